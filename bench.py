@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""Throughput of the per-frame YOLO hot path on N MI355X (frames/s @ 640x640), one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the whole hot path (letterbox/stem -> conv graph -> head decode -> NMS -> scale-back ->
+rows on the host, plus -- for N > 1 -- the per-step gather of rows to rank 0) over one batch of synthetic
+640x640 BGR frames per GPU.  Frames are resident in HBM when the timed region starts.  Weak scaling: the
+per-GPU batch is fixed.  Rank 0 prints ONE JSON line (see the contract in the task statement).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3        # MI355X fp32 matrix (= vector) peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="yolov8n")
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--chunk", type=int, default=0, help="engine batch_chunk (0 = engine default)")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=8)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the hot path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from cvsd_amd import YOLO
+    from cvsd_amd import dist as cdist
+    from cvsd_amd.weights import build_from_state_dict
+    from tools import synth
+
+    # ---- C1: rank 0 builds the synthetic checkpoint, everyone receives the weight image over RCCL ----
+    blob = None
+    prog, sd = None, None
+    if rank == 0:
+        prog, sd = synth.synthetic_checkpoint(args.model, seed=0)
+        blob = build_from_state_dict(args.model, sd)
+    blob = cdist.broadcast_weights(blob)
+    model = YOLO(blob, device=local_rank, batch_chunk=args.chunk)
+    layers, params, _, gflops = model.info()
+
+    # ---- synthetic frames of this rank's shard, resident in HBM ----
+    B = args.batch
+    lo, hi = cdist.shard_range(B * world, rank, world)
+    frames_np = synth.synthetic_frames(min(B, 16), args.size, args.size, seed=1000 + rank)
+    reps = (B + len(frames_np) - 1) // len(frames_np)
+    frames_np = np.concatenate([frames_np] * reps)[:B]
+    frames = torch.from_numpy(frames_np).cuda()
+    torch.cuda.synchronize()
+
+    def step():
+        res = model._infer_rows(frames, 0.25, 0.7, None, 300, args.size)
+        if world > 1:
+            rows, counts, _ = res
+            return cdist.gather_rows(rows, counts)
+        return res
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel (implicit-GEMM conv), HIP events on the engine's stream ----
+    model.set_profiling(True)
+    conv_ms = total_ms = 0.0
+    launches = 0
+    kinds = {}
+    PROF_STEPS = 3
+    for _ in range(PROF_STEPS):
+        model._infer_rows(frames, 0.25, 0.7, None, 300, args.size)
+        t = model.last_timing()
+        conv_ms += t["conv_ms"]
+        launches += t["conv_launches"]
+        total_ms += t["total_ms"]
+        for k in ("stem_ms", "conv_ms", "pool_ms", "upsample_ms", "letterbox_ms", "decode_ms", "nms_ms"):
+            kinds[k] = kinds.get(k, 0.0) + t[k] / PROF_STEPS
+    model.set_profiling(False)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    from cvsd_amd.graph import build_program, parse_model_name
+    pg = build_program(*parse_model_name(args.model))
+    scale = (args.size / 640.0) ** 2
+    conv_flops_frame = 2.0 * sum(c.cout * c.cin * c.k * c.k * (640 // c.stride_div) ** 2 for c in pg.convs if c.cin != 3) * scale
+    achieved = conv_flops_frame * B * PROF_STEPS / (conv_ms * 1e-3) / 1e12
+    fps = world * B * args.steps / dt
+    line = {
+        "metric": "frames/s @640x640", "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.model} {args.size}x{args.size} synthetic BGR frames, batch {B}/GPU/step, "
+                               f"predict conf=0.25 iou=0.7 max_det=300 (letterbox+stem, conv graph, decode, NMS, rows to host)",
+                   "global_batch": B * world, "params": params, "gflop_per_frame": round(gflops * scale, 3),
+                   "parallelism": f"frame-sharded dp{world}"},
+        "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (all instances)", "achieved": round(achieved, 2),
+                     "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4),
+                     "traffic": None, "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
+                     "launches_per_step": launches // PROF_STEPS,
+                     "flop_per_launch_avg": conv_flops_frame * B * PROF_STEPS / max(launches, 1)},
+        "device_ms_per_step": {k: round(v, 3) for k, v in kinds.items()},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args, sd, frames_np, model)
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, sd, frames_np, model):
+    """The torch-CPU oracle (a restatement of the Ultralytics CPU path: kind 'port') timed on the host cores on a
+    bounded sample of the same workload; the same frames go through the GPU path for a parity figure."""
+    import torch
+    from oracle import yolo_oracle as O
+    om = O.OracleModel(args.model, sd)
+    n = min(args.cpu_frames, len(frames_np))
+    sample = list(frames_np[:n])
+    O.predict(om, sample[:2], imgsz=args.size)                     # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        want, _ = O.predict(om, sample, imgsz=args.size)
+        reps += 1
+        if time.perf_counter() - t0 > 10.0 or reps >= 5:
+            break
+    dt = time.perf_counter() - t0
+    got = model.predict(frames_np[:n], imgsz=args.size)
+    same = sum(int(np.array_equal(g.anchor_idx, w["anchor_idx"].numpy())) for g, w in zip(got, want))
+    err = 0.0
+    for g, w in zip(got, want):
+        if np.array_equal(g.anchor_idx, w["anchor_idx"].numpy()) and len(g.anchor_idx):
+            err = max(err, float(np.abs(g.boxes.data.numpy()[:, :4] - w["boxes"].numpy()[:, :4]).max()))
+    return {"value": round(n * reps / dt, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} of the benchmark frames x {reps} passes through oracle/yolo_oracle.py (torch {torch.__version__} "
+                      f"CPU fp32, batch {n})",
+            "parity_vs_gpu": {"frames_with_identical_indices": same, "frames": n, "max_box_abs_err_px": err}}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+// Shared declarations of the engine's translation units (host side + kernel launchers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace mi355 {
+
+// ---- conv (implicit GEMM on the fp32 MFMA pipe), conv_igemm.hip ------------------------------------------
+// Activations are NHWC fp32; a tensor is a channel slice of a buffer: base pointer already offset to the
+// slice's first channel, `cs` = pixel stride of the buffer in floats (multiple of 4).
+struct ConvArgs {
+    const float* src; int src_cs;
+    float* dst;       int dst_cs;
+    const float* res; int res_cs;      // residual slice added after the activation, or nullptr
+    const float* wpk;                  // packed weights (pack_conv_weights)
+    const float* bias;                 // padded to a multiple of 16 floats
+    int B, Hin, Win, Hout, Wout;
+    int Cin, Cout;
+    int k, stride, pad, act;           // k in {1,3}; act: 0 none, 1 SiLU
+};
+// number of floats pack_conv_weights writes: ceil(cout/16) * k*k * ceil(cin/16) * 256
+size_t packed_weight_floats(int cout, int cin, int k);
+// OIHW fp32 -> MFMA fragment order [cout_tile][tap][cin_block][lane(64)][4]
+void pack_conv_weights(const float* w_oihw, int cout, int cin, int k, float* out);
+struct ConvKArgs {
+    const float* src; float* dst; const float* res; const float* wpk; const float* bias;
+    int src_cs, dst_cs, res_cs;
+    int Hin, Win, Hout, Wout, Cin, Cout;
+    int cib, n_ctiles, cin4;
+    int ck, ck4_shift, ldp;
+    int TW, TH, tiles_x, tiles_y, TWin, npix_in;
+    float inv_TW, inv_TWin;
+    int pad, act;
+};
+// A planned launch: kernel instance, grid, LDS bytes and kernel arguments.  Planning (tile / wave-arrangement
+// search) is done once per (op, shape) by the engine; run_conv only enqueues.
+struct ConvLaunch { const void* fn; unsigned grid_x, grid_y; size_t lds; ConvKArgs a; int CT, WP; double flops; };
+const char* plan_conv(const ConvArgs& c, ConvLaunch* out);
+const char* run_conv(const ConvLaunch& l, hipStream_t st);
+
+// ---- misc kernels, misc_kernels.hip ---------------------------------------------------------------------
+struct StemArgs {
+    const uint8_t* img;                // letterboxed BGR u8 [B][H][W][3], dense
+    float* dst; int dst_cs;
+    const float* w;                    // device, OIHW fused [Cout][3][k][k]
+    const float* bias;                 // device [Cout]
+    const float* lut;                  // device [256]: (float)i / 255.0f
+    int B, H, W, Hout, Wout, Cout, k, stride, pad;
+};
+const char* launch_stem(const StemArgs& a, hipStream_t st);
+const char* launch_upsample2x(const float* src, int src_cs, float* dst, int dst_cs, int B, int H, int W, int C,
+                              hipStream_t st);
+// SPPF: x1 = maxpool5(x0), x2 = maxpool5(x1), x3 = maxpool5(x2) (stride 1, -inf padding); src = x0 slice (C ch),
+// dst = slice of 3*C channels receiving x1|x2|x3.
+const char* launch_sppf_pools(const float* src, int src_cs, float* dst, int dst_cs, int B, int H, int W, int C,
+                              hipStream_t st);
+struct LetterboxArgs {
+    const uint8_t* src; int H, W; long long frame_stride; int row_stride;   // source frames
+    uint8_t* dst; int Hd, Wd;                                               // letterboxed output (dense)
+    int top, left, Hr, Wr;                                                  // resized region placement / size
+    const int* xtab;   // device [Wr*3]: x0, coef0, coef1 (11-bit fixed point)
+    const int* ytab;   // device [Hr*3]
+    int resize;        // 0: plain copy of the source into the region
+    int B;
+};
+const char* launch_letterbox(const LetterboxArgs& a, hipStream_t st);
+
+// ---- head decode + NMS, post_kernels.hip ----------------------------------------------------------------
+struct HeadLevelArgs { const float* buf; int cs; int box_off, cls_off, kpt_off; int H, W, stride, anchor0; };
+struct DecodeArgs {
+    HeadLevelArgs lv[4]; int n_levels;
+    int B, A, nc, nkpt, kdim;
+    float* pred;        // [B][A][no] anchor-major decoded tensor (xywh, scores, kpts), no = 4+nc+nkpt*kdim
+    float2* best;       // [B][A] (best score, best class as float)
+};
+const char* launch_decode(const DecodeArgs& a, hipStream_t st);
+// pred in Ultralytics layout [B][no][A] -> anchor-major [B][A][no] plus best[]; used by mi355_op_nms
+const char* launch_best_from_pred(const float* pred_anchor_major, int B, int A, int no, int nc, float2* best,
+                                  hipStream_t st);
+const char* launch_transpose_pred(const float* in, float* out, int B, int rows, int cols, hipStream_t st);
+
+struct NmsArgs {
+    const float* pred; const float2* best;     // as written by decode
+    int B, A, no, nc, nk, kdim;
+    float conf, iou; int max_det; int max_nms; float max_wh;
+    const unsigned* class_mask;                // device bitmask over classes, or nullptr = all
+    unsigned long long* keys;                  // scratch [B][Apow2]
+    int Apow2;
+    // scale-back (A.6); identity when scale_back == 0
+    int scale_back; float gain; float pad_x, pad_y, kpad_x, kpad_y; float orig_w, orig_h;
+    void* out_rows;                            // device mi355_det [B][max_det]
+    int* out_counts;                           // device [B]
+};
+const char* launch_nms(const NmsArgs& a, hipStream_t st);
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace mi355

@@ -1,0 +1,260 @@
+// Fused conv (1x1 / 3x3, stride 1 / 2) + bias + SiLU (+ residual) as an implicit GEMM on the CDNA4 fp32
+// matrix pipe (v_mfma_f32_16x16x4_f32: exact f32, a k-ordered fma chain, 64 FLOP/clk/SIMD).
+//
+// Replaces ultralytics/nn/modules/conv.py:Conv.forward_fuse (act(conv(x)) with the BN folded) and the
+// residual add of block.py:Bottleneck.forward, reached from /root/reference/model.py:38.
+//
+// GEMM view:  D[cout][pixel] = sum_{tap, ci} W[cout][tap][ci] * X[pixel @ tap][ci]
+//   MFMA A operand = weights  (row = cout,  k = input channel)   -> read from HBM/L2 in pre-packed
+//                                                                   fragment order (1 KiB per wave load)
+//   MFMA B operand = pixels   (col = pixel, k = input channel)   -> read from an LDS-staged NHWC halo tile
+//   so the accumulator of a lane holds 4 CONSECUTIVE couts of ONE pixel: the epilogue is one 16-byte store.
+// The k index inside a 16-channel block is permuted (MFMA step s covers channels {4g+s}) so that a lane's
+// four k-steps are one aligned float4 in both operands (ds_read_b128 / global_load_dwordx4).
+//
+// Block = 256 threads = 4 waves, arranged WP (along pixels) x WC (along couts); a wave owns PT pixel tiles
+// x CT cout tiles of 16x16.  The input tile (with halo) is staged through LDS in chunks of `ck` channels.
+#include "common.h"
+
+namespace mi355 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+
+template <int KS, int STRIDE, int PT, int CT, int WP>
+__global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int WC = 4 / WP;
+    constexpr int TAPS = KS * KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave % WP, wc = wave / WP;
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
+    const int ct0 = (blockIdx.y * WC + wc) * CT;
+    const int npix = a.TW * a.TH;
+
+    int xoff[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        int p = (wp * PT + pt) * 16 + (lane & 15);
+        p = p < npix ? p : 0;
+        const int ly = (int)(((float)p + 0.5f) * a.inv_TW);
+        const int lx = p - ly * a.TW;
+        xoff[pt] = ((ly * STRIDE) * a.TWin + lx * STRIDE) * a.ldp + (lane >> 4) * 4;
+    }
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* srcb = a.src + (size_t)b * a.Hin * a.Win * a.src_cs;
+    const int ck4m = (a.ck >> 2) - 1;
+    const int total_f4 = a.npix_in << a.ck4_shift;
+
+    for (int c0 = 0; c0 < a.Cin; c0 += a.ck) {
+        if (c0) __syncthreads();
+        // ---- stage the halo tile, channels [c0, c0+ck), zero-filled outside the image / beyond Cin ----
+        for (int idx = tid; idx < total_f4; idx += 256) {
+            const int pix = idx >> a.ck4_shift, q = idx & ck4m;
+            const int iy = (int)(((float)pix + 0.5f) * a.inv_TWin);
+            const int ix = pix - iy * a.TWin;
+            const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + 4 * q;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && c < a.cin4)
+                v = *(const f32x4*)(srcb + ((size_t)gy * a.Win + gx) * a.src_cs + c);
+            *(f32x4*)(lds + pix * a.ldp + 4 * q) = v;
+        }
+        __syncthreads();
+        const int rem = a.Cin - c0;
+        const int nkk = ((rem < a.ck ? rem : a.ck) + 15) >> 4;
+        const int cib0 = c0 >> 4;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int tapoff = ((tap / KS) * a.TWin + (tap % KS)) * a.ldp;
+            for (int kk = 0; kk < nkk; ++kk) {
+                f32x4 wf[CT], xf[PT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int ctile = ct0 + ct;
+                    wf[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (ctile < a.n_ctiles)
+                        wf[ct] = *(const f32x4*)(a.wpk + ((size_t)(ctile * TAPS + tap) * a.cib + cib0 + kk) * 256 + lane * 4);
+                }
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) xf[pt] = *(const f32x4*)(lds + xoff[pt] + tapoff + kk * 16);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt)
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][s], xf[pt][s], acc[ct][pt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: bias + SiLU (+ residual), 4 consecutive couts of one pixel per lane ----
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int p = (wp * PT + pt) * 16 + (lane & 15);
+        const int pp = p < npix ? p : 0;
+        const int ly = (int)(((float)pp + 0.5f) * a.inv_TW);
+        const int lx = pp - ly * a.TW;
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        const bool ok = (p < npix) && (oy < a.Hout) && (ox < a.Wout);
+        const size_t po = ((size_t)b * a.Hout + oy) * a.Wout + ox;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = (ct0 + ct) * 16 + (lane >> 4) * 4;
+            if (!ok || c >= a.Cout) continue;
+            f32x4 v = acc[ct][pt] + *(const f32x4*)(a.bias + c);
+            if (a.act) {
+                v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
+            }
+            float* d = a.dst + po * a.dst_cs + c;
+            if (c + 3 < a.Cout) {
+                if (a.res) v += *(const f32x4*)(a.res + po * a.res_cs + c);
+                *(f32x4*)d = v;
+            } else {
+                for (int i = 0; i < 4 && c + i < a.Cout; ++i) {
+                    float r = v[i];
+                    if (a.res) r += a.res[po * a.res_cs + c + i];
+                    d[i] = r;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+size_t packed_weight_floats(int cout, int cin, int k) {
+    return (size_t)((cout + 15) / 16) * k * k * ((cin + 15) / 16) * 256;
+}
+
+void pack_conv_weights(const float* w, int cout, int cin, int k, float* out) {
+    const int nct = (cout + 15) / 16, cib = (cin + 15) / 16, taps = k * k;
+    for (int ct = 0; ct < nct; ++ct)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int cb = 0; cb < cib; ++cb) {
+                float* o = out + ((size_t)(ct * taps + tap) * cib + cb) * 256;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s = 0; s < 4; ++s) {
+                        const int co = ct * 16 + (lane & 15);
+                        const int ci = cb * 16 + 4 * (lane >> 4) + s;
+                        o[lane * 4 + s] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * taps + tap] : 0.f;
+                    }
+            }
+}
+
+namespace {
+
+struct Plan { int CT, WP, TW, TH, ck; size_t lds; double cost; };
+
+typedef void (*KernelFn)(ConvKArgs);
+
+template <int KS, int STRIDE, int CT, int WP>
+KernelFn inst() { return &conv_igemm_f32<KS, STRIDE, (CT == 5 ? 3 : 4), CT, WP>; }
+
+template <int KS, int STRIDE>
+KernelFn pick_ct_wp(int CT, int WP) {
+#define MI355_CASE(ct, wp) if (CT == ct && WP == wp) return inst<KS, STRIDE, ct, wp>();
+    MI355_CASE(1, 4) MI355_CASE(2, 4) MI355_CASE(3, 4) MI355_CASE(4, 4) MI355_CASE(5, 4)
+    MI355_CASE(1, 2) MI355_CASE(2, 2) MI355_CASE(3, 2) MI355_CASE(4, 2) MI355_CASE(5, 2)
+    MI355_CASE(1, 1) MI355_CASE(2, 1) MI355_CASE(3, 1) MI355_CASE(4, 1) MI355_CASE(5, 1)
+#undef MI355_CASE
+    return nullptr;
+}
+
+KernelFn pick_kernel(int ks, int stride, int CT, int WP) {
+    if (ks == 1 && stride == 1) return pick_ct_wp<1, 1>(CT, WP);
+    if (ks == 3 && stride == 1) return pick_ct_wp<3, 1>(CT, WP);
+    if (ks == 3 && stride == 2) return pick_ct_wp<3, 2>(CT, WP);
+    return nullptr;
+}
+
+constexpr size_t LDS_SOFT = 40 * 1024, LDS_HARD = 64 * 1024;
+
+// choose the wave arrangement, the output tile and the staged channel count for one conv
+Plan make_plan(int H, int W, int n_ctiles, int cin, int ks, int stride) {
+    Plan best{}; best.cost = 1e30;
+    const int cin16 = round_up(cin, 16);
+    for (int WC = 1; WC <= 4; WC *= 2)
+        for (int CT = 1; CT <= 5; ++CT) {
+            const int WP = 4 / WC, PT = (CT == 5 ? 3 : 4), P = WP * PT * 16;
+            const int cover = CT * WC, nblk = (n_ctiles + cover - 1) / cover;
+            const double waste_c = (double)nblk * cover / n_ctiles;
+            for (int TW = 1; TW <= P && TW <= W; ++TW) {
+                int TH = P / TW; if (TH > H) TH = H;
+                if (TH < 1) continue;
+                const long tiles = (long)((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+                const int THin = (TH - 1) * stride + ks, TWin = (TW - 1) * stride + ks;
+                const size_t lds16 = (size_t)THin * TWin * (16 + 4) * 4;
+                if (lds16 > LDS_HARD) continue;
+                int ck = 16;
+                for (int c = 64; c >= 16; c >>= 1)
+                    if (c <= cin16 && (size_t)THin * TWin * (c + 4) * 4 <= LDS_SOFT) { ck = c; break; }
+                const double infl = waste_c * (double)tiles * P / ((double)W * H);
+                const double halo = (double)THin * TWin / ((double)TH * TW * stride * stride);
+                double cost = infl * (1.0 + 0.03 * halo * nblk) + (lds16 > LDS_SOFT ? 0.3 : 0.0) - 0.002 * CT;
+                if (cost < best.cost) best = Plan{CT, WP, TW, TH, ck, (size_t)THin * TWin * (ck + 4) * 4, cost};
+            }
+        }
+    return best;
+}
+
+}  // namespace
+
+const char* plan_conv(const ConvArgs& c, ConvLaunch* out) {
+    if (!((c.k == 1 && c.stride == 1) || (c.k == 3 && (c.stride == 1 || c.stride == 2))))
+        return "conv: only 1x1/s1, 3x3/s1 and 3x3/s2 are supported";
+    if ((c.src_cs & 3) || (c.dst_cs & 3) || (c.res && (c.res_cs & 3))) return "conv: channel strides must be multiples of 4";
+    if (((uintptr_t)c.src | (uintptr_t)c.dst | (uintptr_t)c.res | (uintptr_t)c.wpk | (uintptr_t)c.bias) & 15)
+        return "conv: pointers must be 16-byte aligned";
+    ConvKArgs a{};
+    a.src = c.src; a.dst = c.dst; a.res = c.res; a.wpk = c.wpk; a.bias = c.bias;
+    a.src_cs = c.src_cs; a.dst_cs = c.dst_cs; a.res_cs = c.res_cs;
+    a.Cin = c.Cin; a.Cout = c.Cout; a.pad = c.pad; a.act = c.act;
+    a.cib = (c.Cin + 15) / 16; a.n_ctiles = (c.Cout + 15) / 16; a.cin4 = round_up(c.Cin, 4);
+    int B = c.B;
+    if (c.k == 1) {   // pointwise: flatten batch and space into one row of pixels
+        a.Hin = 1; a.Win = c.B * c.Hin * c.Win; a.Hout = 1; a.Wout = a.Win; B = 1;
+    } else {
+        a.Hin = c.Hin; a.Win = c.Win; a.Hout = c.Hout; a.Wout = c.Wout;
+    }
+    const Plan p = make_plan(a.Hout, a.Wout, a.n_ctiles, c.Cin, c.k, c.stride);
+    if (p.cost >= 1e30) return "conv: no launch plan fits in LDS";
+    KernelFn fn = pick_kernel(c.k, c.stride, p.CT, p.WP);
+    if (!fn) return "conv: no kernel instance";
+    a.TW = p.TW; a.TH = p.TH;
+    a.tiles_x = (a.Wout + p.TW - 1) / p.TW; a.tiles_y = (a.Hout + p.TH - 1) / p.TH;
+    a.TWin = (p.TW - 1) * c.stride + c.k;
+    const int THin = (p.TH - 1) * c.stride + c.k;
+    a.npix_in = a.TWin * THin;
+    a.inv_TW = 1.0f / (float)p.TW; a.inv_TWin = 1.0f / (float)a.TWin;
+    a.ck = p.ck; a.ldp = p.ck + 4;
+    a.ck4_shift = (p.ck == 64 ? 4 : p.ck == 32 ? 3 : 2);
+    const int WC = 4 / p.WP;
+    out->fn = (const void*)fn;
+    out->grid_x = (unsigned)((long)B * a.tiles_x * a.tiles_y);
+    out->grid_y = (unsigned)((a.n_ctiles + p.CT * WC - 1) / (p.CT * WC));
+    out->lds = p.lds;
+    out->a = a;
+    out->CT = p.CT; out->WP = p.WP;
+    out->flops = 2.0 * c.B * c.Hout * c.Wout * (double)c.Cout * c.Cin * c.k * c.k;
+    return nullptr;
+}
+
+const char* run_conv(const ConvLaunch& l, hipStream_t st) {
+    hipLaunchKernelGGL((KernelFn)l.fn, dim3(l.grid_x, l.grid_y), dim3(256), l.lds, st, l.a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+}  // namespace mi355

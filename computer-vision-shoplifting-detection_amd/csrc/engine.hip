@@ -1,0 +1,772 @@
+// Host side of libmi355yolo.so: .mi355w reader, memory plan, launch sequence and the C ABI of
+// include/mi355_yolo.h.  Replaces what the reference reaches through ultralytics (model.py:18,38):
+// Model.__init__/AutoBackend (weights + fuse), BasePredictor.stream_inference (preprocess -> model -> postprocess).
+#include "common.h"
+#include "../../include/mi355_yolo.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace mi355 {
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(MI355_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+#define KCHK(expr)                                                                           \
+    do {                                                                                     \
+        const char* m_ = (expr);                                                             \
+        if (m_) return fail(MI355_EHIP, std::string("launch failed: ") + m_);                \
+    } while (0)
+
+enum { OP_STEM = 0, OP_CONV = 1, OP_UPSAMPLE = 2, OP_SPPF_POOL = 3 };
+
+#pragma pack(push, 1)
+struct FileHeader {
+    char magic[8];
+    uint32_t version, header_bytes;
+    uint32_t family, scale, task, nc, nkpt, kdim, reg_max;
+    uint32_t n_buffers, n_ops, n_convs, n_levels;
+    uint32_t json_off, json_bytes;
+    uint64_t data_bytes;
+};
+struct FileBuf { uint32_t channels, stride_div; };
+struct FileOp { int32_t type, k, s, act, src_buf, src_choff, src_c, dst_buf, dst_choff, dst_c, res_buf, res_choff, conv, pad, r0, r1; };
+struct FileConv { char name[64]; uint32_t cin, cout, k, s, pad, act; uint64_t w_off, b_off; };
+struct FileLevel { uint32_t buf, box_off, cls_off, kpt_off, stride; };
+#pragma pack(pop)
+
+struct DevConv { float* wpk = nullptr; float* bias = nullptr; float* w_raw = nullptr; };
+
+// LetterBox geometry (data/augment.py:LetterBox, auto=True, scaleup=True, center=True, stride 32) and the
+// scale-back constants of utils/ops.py:scale_boxes / scale_coords, in the same double arithmetic as Python.
+struct Geometry {
+    int h0, w0, Hl, Wl;          // original and letterboxed size
+    int Hr, Wr, top, left;       // resized region
+    bool resize, identity;
+    double gain; double pad_x, pad_y, kpad_x, kpad_y;
+};
+
+static double py_round(double x) { return std::nearbyint(x); }   // round-half-even, like Python's round()
+
+static Geometry make_geometry(int h0, int w0, int imgsz) {
+    Geometry g{};
+    g.h0 = h0; g.w0 = w0;
+    const double r = std::min((double)imgsz / h0, (double)imgsz / w0);
+    g.Wr = (int)py_round(w0 * r); g.Hr = (int)py_round(h0 * r);
+    double dw = imgsz - g.Wr, dh = imgsz - g.Hr;
+    dw = std::fmod(dw, 32.0); dh = std::fmod(dh, 32.0);
+    dw /= 2; dh /= 2;
+    const int top = (int)py_round(dh - 0.1), bottom = (int)py_round(dh + 0.1);
+    const int left = (int)py_round(dw - 0.1), right = (int)py_round(dw + 0.1);
+    g.top = top; g.left = left;
+    g.Hl = g.Hr + top + bottom; g.Wl = g.Wr + left + right;
+    g.resize = (g.Wr != w0) || (g.Hr != h0);
+    g.identity = !g.resize && top == 0 && left == 0 && bottom == 0 && right == 0;
+    g.gain = std::min((double)g.Hl / h0, (double)g.Wl / w0);
+    g.pad_x = py_round((g.Wl - w0 * g.gain) / 2 - 0.1);
+    g.pad_y = py_round((g.Hl - h0 * g.gain) / 2 - 0.1);
+    g.kpad_x = (g.Wl - w0 * g.gain) / 2;
+    g.kpad_y = (g.Hl - h0 * g.gain) / 2;
+    return g;
+}
+
+// cv2.resize(INTER_LINEAR) coefficient table: for each destination index: source index, 2 taps in 1/2048 units
+static void resize_table(int dn, int sn, std::vector<int>& tab) {
+    tab.resize((size_t)dn * 3);
+    const double scale = (double)sn / dn;
+    for (int d = 0; d < dn; ++d) {
+        float fx = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(fx);
+        fx -= (float)s;
+        if (s < 0) { s = 0; fx = 0.f; }
+        if (s >= sn - 1) { s = sn - 1; fx = 0.f; }
+        tab[d * 3] = s;
+        tab[d * 3 + 1] = (int)std::lrintf((1.f - fx) * 2048.f);
+        tab[d * 3 + 2] = (int)std::lrintf(fx * 2048.f);
+    }
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+struct mi355_yolo {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    FileHeader hdr{};
+    std::vector<FileBuf> bufs;
+    std::vector<FileOp> ops;
+    std::vector<FileConv> convs;
+    std::vector<FileLevel> levels;
+    std::vector<DevConv> dconv;
+    float* lut = nullptr;
+    int chunk = 16;
+    long long n_params = 0, macs640 = 0;
+
+    // per-shape state
+    int cur_nb = 0, cur_H = 0, cur_W = 0;
+    std::vector<float*> dbuf;           // activation buffers
+    std::vector<int> dbuf_cs;
+    std::vector<ConvLaunch> plans;      // per op (valid for OP_CONV)
+    float* pred = nullptr; float2* best = nullptr; unsigned long long* keys = nullptr;
+    int A = 0, Apow2 = 0;
+    uint8_t* lbox = nullptr;            // letterboxed frames of one chunk
+    // per-call scratch (grown on demand)
+    uint8_t* d_in = nullptr; size_t d_in_bytes = 0;
+    mi355_det* d_rows = nullptr; int* d_counts = nullptr; size_t rows_cap = 0; int counts_cap = 0;
+    mi355_det* h_rows = nullptr; int* h_counts = nullptr; size_t h_rows_cap = 0; int h_counts_cap = 0;
+    unsigned* d_cmask = nullptr; unsigned* h_cmask = nullptr; int cmask_words = 0;
+    int* d_xtab = nullptr; int* d_ytab = nullptr; int tab_h0 = -1, tab_w0 = -1, tab_imgsz = -1;
+    float* d_rawhead = nullptr; size_t rawhead_floats = 0;
+    // timing
+    bool profiling = false;
+    mi355_timing last{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> pev;        // profiling events
+
+    int no() const { return 4 + (int)hdr.nc + (int)(hdr.nkpt * hdr.kdim); }
+    void free_shape();
+    ~mi355_yolo();
+};
+
+void mi355_yolo::free_shape() {
+    for (float* p : dbuf) if (p) (void)hipFree(p);
+    dbuf.clear(); dbuf_cs.clear(); plans.clear();
+    if (pred) (void)hipFree(pred); if (best) (void)hipFree(best); if (keys) (void)hipFree(keys);
+    if (lbox) (void)hipFree(lbox);
+    pred = nullptr; best = nullptr; keys = nullptr; lbox = nullptr;
+    cur_nb = cur_H = cur_W = 0;
+}
+
+mi355_yolo::~mi355_yolo() {
+    (void)hipSetDevice(device);
+    free_shape();
+    for (auto& c : dconv) { if (c.wpk) (void)hipFree(c.wpk); if (c.bias) (void)hipFree(c.bias); if (c.w_raw) (void)hipFree(c.w_raw); }
+    if (lut) (void)hipFree(lut);
+    if (d_in) (void)hipFree(d_in);
+    if (d_rows) (void)hipFree(d_rows); if (d_counts) (void)hipFree(d_counts);
+    if (h_rows) (void)hipHostFree(h_rows); if (h_counts) (void)hipHostFree(h_counts);
+    if (d_cmask) (void)hipFree(d_cmask); if (h_cmask) (void)hipHostFree(h_cmask);
+    if (d_xtab) (void)hipFree(d_xtab); if (d_ytab) (void)hipFree(d_ytab);
+    if (d_rawhead) (void)hipFree(d_rawhead);
+    if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1);
+    for (auto e : pev) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+namespace mi355 {
+
+static int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
+    if (n < sizeof(FileHeader) || std::memcmp(blob, "MI355YW1", 8) != 0) return fail(MI355_EFORMAT, "not a .mi355w file (bad magic)");
+    std::memcpy(&h->hdr, blob, sizeof(FileHeader));
+    const FileHeader& H = h->hdr;
+    if (H.version != 1) return fail(MI355_EFORMAT, "unsupported .mi355w version");
+    size_t p = sizeof(FileHeader);
+    const size_t need = p + sizeof(FileBuf) * H.n_buffers + sizeof(FileOp) * H.n_ops + sizeof(FileConv) * H.n_convs +
+                        sizeof(FileLevel) * H.n_levels;
+    if (need > n || (size_t)H.header_bytes + H.data_bytes > n || H.n_levels > 4 || H.n_levels < 1)
+        return fail(MI355_EFORMAT, ".mi355w file is truncated or inconsistent");
+    h->bufs.resize(H.n_buffers); std::memcpy(h->bufs.data(), blob + p, sizeof(FileBuf) * H.n_buffers); p += sizeof(FileBuf) * H.n_buffers;
+    h->ops.resize(H.n_ops);      std::memcpy(h->ops.data(), blob + p, sizeof(FileOp) * H.n_ops);       p += sizeof(FileOp) * H.n_ops;
+    h->convs.resize(H.n_convs);  std::memcpy(h->convs.data(), blob + p, sizeof(FileConv) * H.n_convs); p += sizeof(FileConv) * H.n_convs;
+    h->levels.resize(H.n_levels); std::memcpy(h->levels.data(), blob + p, sizeof(FileLevel) * H.n_levels);
+    if (H.nkpt * H.kdim > MI355_MAX_KPT_FLOATS) return fail(MI355_EFORMAT, "keypoint shape larger than 17x3 is not supported");
+    // validate the program
+    for (const FileOp& o : h->ops) {
+        auto okv = [&](int b, int off, int c) { return b >= 0 && b < (int)H.n_buffers && off >= 0 && (off & 3) == 0 && off + c <= (int)h->bufs[b].channels; };
+        if (o.type != OP_STEM && !okv(o.src_buf, o.src_choff, o.src_c)) return fail(MI355_EFORMAT, "op reads outside its buffer");
+        if (!okv(o.dst_buf, o.dst_choff, o.type == OP_SPPF_POOL ? 3 * o.src_c : o.dst_c)) return fail(MI355_EFORMAT, "op writes outside its buffer");
+        if (o.res_buf >= 0 && !okv(o.res_buf, o.res_choff, o.dst_c)) return fail(MI355_EFORMAT, "residual outside its buffer");
+        if ((o.type == OP_STEM || o.type == OP_CONV) && (o.conv < 0 || o.conv >= (int)H.n_convs)) return fail(MI355_EFORMAT, "bad conv index");
+    }
+    h->n_params = H.reg_max; h->macs640 = 0;
+    for (const FileOp& o : h->ops) {
+        if (o.type != OP_STEM && o.type != OP_CONV) continue;
+        const FileConv& c = h->convs[o.conv];
+        const long long sd = h->bufs[o.dst_buf].stride_div;
+        h->n_params += (long long)c.cout * c.cin * c.k * c.k + c.cout;
+        h->macs640 += (long long)c.cout * c.cin * c.k * c.k * (640 / sd) * (640 / sd);
+    }
+    // upload weights
+    const uint8_t* data = blob + H.header_bytes;
+    h->dconv.resize(H.n_convs);
+    std::vector<float> tmp;
+    for (size_t i = 0; i < h->convs.size(); ++i) {
+        const FileConv& c = h->convs[i];
+        const size_t wn = (size_t)c.cout * c.cin * c.k * c.k;
+        if (c.w_off + wn * 4 > H.data_bytes || c.b_off + (size_t)c.cout * 4 > H.data_bytes) return fail(MI355_EFORMAT, "tensor outside the data region");
+        const float* w = (const float*)(data + c.w_off);
+        const float* b = (const float*)(data + c.b_off);
+        DevConv& d = h->dconv[i];
+        const int bn = round_up((int)c.cout, 16);
+        tmp.assign(bn, 0.f);
+        std::memcpy(tmp.data(), b, (size_t)c.cout * 4);
+        HIPCHK(hipMalloc(&d.bias, bn * 4));
+        HIPCHK(hipMemcpy(d.bias, tmp.data(), bn * 4, hipMemcpyHostToDevice));
+        if (c.cin == 3) {                      // stem: raw OIHW, read by stem_conv_u8
+            HIPCHK(hipMalloc(&d.w_raw, wn * 4));
+            HIPCHK(hipMemcpy(d.w_raw, w, wn * 4, hipMemcpyHostToDevice));
+        } else {
+            const size_t pn = packed_weight_floats(c.cout, c.cin, c.k);
+            tmp.resize(pn);
+            pack_conv_weights(w, c.cout, c.cin, c.k, tmp.data());
+            HIPCHK(hipMalloc(&d.wpk, pn * 4));
+            HIPCHK(hipMemcpy(d.wpk, tmp.data(), pn * 4, hipMemcpyHostToDevice));
+        }
+    }
+    float lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = (float)i / 255.0f;     // im /= 255 (IEEE fp32 division)
+    HIPCHK(hipMalloc(&h->lut, sizeof(lut)));
+    HIPCHK(hipMemcpy(h->lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+    return MI355_OK;
+}
+
+static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
+    if (h->cur_nb == nb && h->cur_H == Hl && h->cur_W == Wl) return MI355_OK;
+    h->free_shape();
+    if ((Hl % 32) || (Wl % 32)) return fail(MI355_EINVAL, "letterboxed size must be a multiple of 32");
+    const size_t nbufs = h->bufs.size();
+    h->dbuf.assign(nbufs, nullptr); h->dbuf_cs.assign(nbufs, 0);
+    for (size_t i = 0; i < nbufs; ++i) {
+        const int cs = round_up((int)h->bufs[i].channels, 4);
+        const size_t bytes = (size_t)nb * (Hl / h->bufs[i].stride_div) * (Wl / h->bufs[i].stride_div) * cs * 4;
+        HIPCHK(hipMalloc(&h->dbuf[i], bytes));
+        HIPCHK(hipMemsetAsync(h->dbuf[i], 0, bytes, h->stream));   // pad channels stay zero forever
+        h->dbuf_cs[i] = cs;
+    }
+    h->plans.assign(h->ops.size(), ConvLaunch{});
+    for (size_t i = 0; i < h->ops.size(); ++i) {
+        const FileOp& o = h->ops[i];
+        if (o.type != OP_CONV) continue;
+        const FileConv& c = h->convs[o.conv];
+        ConvArgs a{};
+        const int sd_in = h->bufs[o.src_buf].stride_div, sd_out = h->bufs[o.dst_buf].stride_div;
+        a.src = h->dbuf[o.src_buf] + o.src_choff; a.src_cs = h->dbuf_cs[o.src_buf];
+        a.dst = h->dbuf[o.dst_buf] + o.dst_choff; a.dst_cs = h->dbuf_cs[o.dst_buf];
+        if (o.res_buf >= 0) { a.res = h->dbuf[o.res_buf] + o.res_choff; a.res_cs = h->dbuf_cs[o.res_buf]; }
+        a.wpk = h->dconv[o.conv].wpk; a.bias = h->dconv[o.conv].bias;
+        a.B = nb; a.Hin = Hl / sd_in; a.Win = Wl / sd_in; a.Hout = Hl / sd_out; a.Wout = Wl / sd_out;
+        a.Cin = c.cin; a.Cout = c.cout; a.k = c.k; a.stride = c.s; a.pad = c.pad; a.act = c.act;
+        if (a.Hout * (int)c.s != a.Hin || a.Wout * (int)c.s != a.Win) return fail(MI355_EFORMAT, "conv resolution mismatch in program");
+        KCHK(plan_conv(a, &h->plans[i]));
+    }
+    int A = 0;
+    for (const FileLevel& lv : h->levels) A += (Hl / lv.stride) * (Wl / lv.stride);
+    h->A = A; h->Apow2 = 1; while (h->Apow2 < A) h->Apow2 <<= 1;
+    HIPCHK(hipMalloc(&h->pred, (size_t)nb * A * h->no() * 4));
+    HIPCHK(hipMalloc(&h->best, (size_t)nb * A * sizeof(float2)));
+    HIPCHK(hipMalloc(&h->keys, (size_t)nb * h->Apow2 * 8));
+    HIPCHK(hipMalloc(&h->lbox, (size_t)nb * Hl * Wl * 3));
+    h->cur_nb = nb; h->cur_H = Hl; h->cur_W = Wl;
+    return MI355_OK;
+}
+
+// event bookkeeping for per-kind timing
+enum Kind { K_LETTERBOX, K_STEM, K_CONV, K_POOL, K_UPSAMPLE, K_DECODE, K_NMS, K_COUNT };
+struct Prof {
+    mi355_yolo* h; size_t used = 0; std::vector<std::pair<int, size_t>> spans;
+    int begin(int kind) {
+        if (!h->profiling) return 0;
+        if (used + 2 > h->pev.size()) { for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return -1; h->pev.push_back(e); } }
+        spans.push_back({kind, used});
+        return hipEventRecord(h->pev[used], h->stream) == hipSuccess ? 0 : -1;
+    }
+    int end() {
+        if (!h->profiling) return 0;
+        const int r = hipEventRecord(h->pev[used + 1], h->stream) == hipSuccess ? 0 : -1;
+        used += 2; return r;
+    }
+};
+
+// run the net (+decode) on nb frames that sit in `frames_dev` (original size h0 x w0, dense)
+static int run_chunk(mi355_yolo* h, Prof& pf, const uint8_t* frames_dev, int nb, const Geometry& g) {
+    const uint8_t* stem_in = frames_dev;
+    if (!g.identity) {
+        LetterboxArgs la{};
+        la.src = frames_dev; la.H = g.h0; la.W = g.w0; la.frame_stride = (long long)g.h0 * g.w0 * 3; la.row_stride = g.w0 * 3;
+        la.dst = h->lbox; la.Hd = g.Hl; la.Wd = g.Wl; la.top = g.top; la.left = g.left; la.Hr = g.Hr; la.Wr = g.Wr;
+        la.xtab = h->d_xtab; la.ytab = h->d_ytab; la.resize = g.resize ? 1 : 0; la.B = nb;
+        if (pf.begin(K_LETTERBOX)) return fail(MI355_EHIP, "event");
+        KCHK(launch_letterbox(la, h->stream));
+        pf.end();
+        stem_in = h->lbox;
+    }
+    for (size_t i = 0; i < h->ops.size(); ++i) {
+        const FileOp& o = h->ops[i];
+        const int sd_out = h->bufs[o.dst_buf].stride_div;
+        float* dst = h->dbuf[o.dst_buf] + o.dst_choff;
+        if (o.type == OP_STEM) {
+            const FileConv& c = h->convs[o.conv];
+            StemArgs s{};
+            s.img = stem_in; s.dst = dst; s.dst_cs = h->dbuf_cs[o.dst_buf];
+            s.w = h->dconv[o.conv].w_raw; s.bias = h->dconv[o.conv].bias; s.lut = h->lut;
+            s.B = nb; s.H = g.Hl; s.W = g.Wl; s.Hout = g.Hl / sd_out; s.Wout = g.Wl / sd_out;
+            s.Cout = c.cout; s.k = c.k; s.stride = c.s; s.pad = c.pad;
+            if (pf.begin(K_STEM)) return fail(MI355_EHIP, "event");
+            KCHK(launch_stem(s, h->stream));
+            pf.end();
+        } else if (o.type == OP_CONV) {
+            ConvLaunch l = h->plans[i];
+            if (nb != h->cur_nb) {             // tail chunk: same buffers, fewer frames
+                if (h->convs[o.conv].k == 1) {
+                    const int sd_in = h->bufs[o.src_buf].stride_div;
+                    l.a.Win = l.a.Wout = nb * (g.Hl / sd_in) * (g.Wl / sd_in);
+                    l.a.tiles_x = (l.a.Wout + l.a.TW - 1) / l.a.TW;
+                    l.grid_x = (unsigned)l.a.tiles_x;
+                } else {
+                    l.grid_x = (unsigned)((long)nb * l.a.tiles_x * l.a.tiles_y);
+                }
+            }
+            if (pf.begin(K_CONV)) return fail(MI355_EHIP, "event");
+            KCHK(run_conv(l, h->stream));
+            pf.end();
+        } else if (o.type == OP_UPSAMPLE) {
+            const int sd_in = h->bufs[o.src_buf].stride_div;
+            if (pf.begin(K_UPSAMPLE)) return fail(MI355_EHIP, "event");
+            KCHK(launch_upsample2x(h->dbuf[o.src_buf] + o.src_choff, h->dbuf_cs[o.src_buf], dst, h->dbuf_cs[o.dst_buf], nb,
+                                   g.Hl / sd_in, g.Wl / sd_in, o.src_c, h->stream));
+            pf.end();
+        } else if (o.type == OP_SPPF_POOL) {
+            if (o.k != 5) return fail(MI355_EFORMAT, "SPPF pool size must be 5");
+            if (pf.begin(K_POOL)) return fail(MI355_EHIP, "event");
+            KCHK(launch_sppf_pools(h->dbuf[o.src_buf] + o.src_choff, h->dbuf_cs[o.src_buf], dst, h->dbuf_cs[o.dst_buf], nb,
+                                   g.Hl / sd_out, g.Wl / sd_out, o.src_c, h->stream));
+            pf.end();
+        } else {
+            return fail(MI355_EFORMAT, "unknown op type in program");
+        }
+    }
+    DecodeArgs d{};
+    d.n_levels = (int)h->levels.size();
+    int a0 = 0;
+    for (int l = 0; l < d.n_levels; ++l) {
+        const FileLevel& lv = h->levels[l];
+        d.lv[l] = HeadLevelArgs{h->dbuf[lv.buf], h->dbuf_cs[lv.buf], (int)lv.box_off, (int)lv.cls_off, (int)lv.kpt_off,
+                                g.Hl / (int)lv.stride, g.Wl / (int)lv.stride, (int)lv.stride, a0};
+        a0 += (g.Hl / lv.stride) * (g.Wl / lv.stride);
+    }
+    d.B = nb; d.A = h->A; d.nc = h->hdr.nc; d.nkpt = h->hdr.nkpt; d.kdim = h->hdr.kdim;
+    d.pred = h->pred; d.best = h->best;
+    if (pf.begin(K_DECODE)) return fail(MI355_EHIP, "event");
+    KCHK(launch_decode(d, h->stream));
+    pf.end();
+    return MI355_OK;
+}
+
+static int prepare_geometry(mi355_yolo* h, const Geometry& g, int imgsz) {
+    if (g.resize && (h->tab_h0 != g.h0 || h->tab_w0 != g.w0 || h->tab_imgsz != imgsz)) {
+        std::vector<int> xt, yt;
+        resize_table(g.Wr, g.w0, xt); resize_table(g.Hr, g.h0, yt);
+        if (h->d_xtab) (void)hipFree(h->d_xtab); if (h->d_ytab) (void)hipFree(h->d_ytab);
+        h->d_xtab = h->d_ytab = nullptr;
+        HIPCHK(hipMalloc(&h->d_xtab, xt.size() * 4)); HIPCHK(hipMalloc(&h->d_ytab, yt.size() * 4));
+        HIPCHK(hipMemcpy(h->d_xtab, xt.data(), xt.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_ytab, yt.data(), yt.size() * 4, hipMemcpyHostToDevice));
+        h->tab_h0 = g.h0; h->tab_w0 = g.w0; h->tab_imgsz = imgsz;
+    }
+    return MI355_OK;
+}
+
+static int collect_timing(mi355_yolo* h, Prof& pf, int frames) {
+    mi355_timing t{};
+    t.frames = frames;
+    (void)hipEventElapsedTime(&t.total_ms, h->ev0, h->ev1);
+    for (auto& sp : pf.spans) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, h->pev[sp.second], h->pev[sp.second + 1]);
+        switch (sp.first) {
+            case K_LETTERBOX: t.letterbox_ms += ms; break;
+            case K_STEM: t.stem_ms += ms; break;
+            case K_CONV: t.conv_ms += ms; t.conv_launches++; break;
+            case K_POOL: t.pool_ms += ms; break;
+            case K_UPSAMPLE: t.upsample_ms += ms; break;
+            case K_DECODE: t.decode_ms += ms; break;
+            case K_NMS: t.nms_ms += ms; break;
+        }
+    }
+    h->last = t;
+    return MI355_OK;
+}
+
+static int infer_impl(mi355_yolo* h, const uint8_t* src, bool src_on_device, int n, int height, int width, int row_stride,
+                      float conf, float iou, const int* classes, int n_classes, int max_det, int imgsz,
+                      mi355_det* out_rows, int cap, int* out_counts) {
+    if (!h || !src || !out_rows || !out_counts) return fail(MI355_EINVAL, "null argument");
+    if (n <= 0 || height <= 0 || width <= 0) return fail(MI355_EINVAL, "n, height and width must be positive");
+    if (max_det <= 0) max_det = 300;
+    if (max_det > 1024) return fail(MI355_EINVAL, "max_det must be <= 1024");
+    if (cap < 1) return fail(MI355_EINVAL, "out_capacity_per_image must be >= 1");
+    if (imgsz <= 0) imgsz = 640;
+    if (imgsz % 32) return fail(MI355_EINVAL, "imgsz must be a multiple of 32");
+    if (row_stride == 0) row_stride = width * 3;
+    if (row_stride < width * 3) return fail(MI355_EINVAL, "row_stride_bytes smaller than a row");
+    if (n_classes < 0 || (n_classes > 0 && !classes)) return fail(MI355_EINVAL, "bad classes argument");
+    HIPCHK(hipSetDevice(h->device));
+    const Geometry g = make_geometry(height, width, imgsz);
+    const int nb = std::min(n, h->chunk);
+    int rc = ensure_shape(h, nb, g.Hl, g.Wl); if (rc) return rc;
+    rc = prepare_geometry(h, g, imgsz); if (rc) return rc;
+
+    const size_t frame_bytes = (size_t)height * width * 3;
+    const uint8_t* dev_frames = src;
+    if (!src_on_device) {
+        if (h->d_in_bytes < frame_bytes * n) {
+            if (h->d_in) (void)hipFree(h->d_in);
+            h->d_in = nullptr; h->d_in_bytes = 0;
+            HIPCHK(hipMalloc(&h->d_in, frame_bytes * n)); h->d_in_bytes = frame_bytes * n;
+        }
+        HIPCHK(hipMemcpy2DAsync(h->d_in, (size_t)width * 3, src, (size_t)row_stride, (size_t)width * 3, (size_t)height * n,
+                                hipMemcpyHostToDevice, h->stream));
+        dev_frames = h->d_in;
+    }
+    if (h->rows_cap < (size_t)n * max_det) {
+        if (h->d_rows) (void)hipFree(h->d_rows); h->d_rows = nullptr; h->rows_cap = 0;
+        HIPCHK(hipMalloc(&h->d_rows, (size_t)n * max_det * sizeof(mi355_det))); h->rows_cap = (size_t)n * max_det;
+    }
+    if (h->counts_cap < 2 * n) {
+        if (h->d_counts) (void)hipFree(h->d_counts); h->d_counts = nullptr; h->counts_cap = 0;
+        HIPCHK(hipMalloc(&h->d_counts, (size_t)2 * n * sizeof(int) + 2 * h->chunk * sizeof(int))); h->counts_cap = 2 * n;
+    }
+    if (h->h_rows_cap < (size_t)n * max_det) {
+        if (h->h_rows) (void)hipHostFree(h->h_rows); h->h_rows = nullptr; h->h_rows_cap = 0;
+        HIPCHK(hipHostMalloc(&h->h_rows, (size_t)n * max_det * sizeof(mi355_det))); h->h_rows_cap = (size_t)n * max_det;
+    }
+    if (h->h_counts_cap < n) {
+        if (h->h_counts) (void)hipHostFree(h->h_counts); h->h_counts = nullptr; h->h_counts_cap = 0;
+        HIPCHK(hipHostMalloc(&h->h_counts, (size_t)n * sizeof(int))); h->h_counts_cap = n;
+    }
+    const unsigned* cmask = nullptr;
+    if (n_classes > 0) {
+        const int words = ((int)h->hdr.nc + 31) / 32;
+        if (h->cmask_words < words) {
+            if (h->d_cmask) (void)hipFree(h->d_cmask); if (h->h_cmask) (void)hipHostFree(h->h_cmask);
+            h->d_cmask = nullptr; h->h_cmask = nullptr; h->cmask_words = 0;
+            HIPCHK(hipMalloc(&h->d_cmask, words * 4)); HIPCHK(hipHostMalloc(&h->h_cmask, words * 4)); h->cmask_words = words;
+        }
+        std::memset(h->h_cmask, 0, words * 4);
+        for (int i = 0; i < n_classes; ++i)
+            if (classes[i] >= 0 && classes[i] < (int)h->hdr.nc) h->h_cmask[classes[i] >> 5] |= 1u << (classes[i] & 31);
+        HIPCHK(hipMemcpyAsync(h->d_cmask, h->h_cmask, words * 4, hipMemcpyHostToDevice, h->stream));
+        cmask = h->d_cmask;
+    }
+
+    Prof pf{h};
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int s = 0; s < n; s += nb) {
+        const int m = std::min(nb, n - s);
+        rc = run_chunk(h, pf, dev_frames + (size_t)s * frame_bytes, m, g); if (rc) return rc;
+        NmsArgs na{};
+        na.pred = h->pred; na.best = h->best; na.B = m; na.A = h->A; na.no = h->no(); na.nc = h->hdr.nc;
+        na.nk = h->hdr.nkpt * h->hdr.kdim; na.kdim = h->hdr.kdim;
+        na.conf = conf; na.iou = iou; na.max_det = max_det; na.max_nms = 30000; na.max_wh = 7680.f;
+        na.class_mask = cmask; na.keys = h->keys; na.Apow2 = h->Apow2;
+        na.scale_back = 1; na.gain = (float)g.gain; na.pad_x = (float)g.pad_x; na.pad_y = (float)g.pad_y;
+        na.kpad_x = (float)g.kpad_x; na.kpad_y = (float)g.kpad_y; na.orig_w = (float)width; na.orig_h = (float)height;
+        na.out_rows = h->d_rows + (size_t)s * max_det;
+        // counts for this chunk are written at [s, s+m); the sort kernel's scratch counts at [.. + m)
+        na.out_counts = h->d_counts + s;
+        // nms kernels use out_counts[B..2B) as scratch: point them past the real counts
+        if (pf.begin(K_NMS)) return fail(MI355_EHIP, "event");
+        {
+            // temporary counts block: [2n .. 2n + 2*chunk)
+            int* tmp = h->d_counts + 2 * n;
+            NmsArgs nb_args = na; nb_args.out_counts = tmp;
+            KCHK(launch_nms(nb_args, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_counts + s, tmp, (size_t)m * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+        }
+        pf.end();
+    }
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_counts, h->d_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_rows, h->d_rows, (size_t)n * max_det * sizeof(mi355_det), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; ++i) {
+        const int c = std::min(h->h_counts[i], cap);
+        out_counts[i] = c;
+        std::memcpy(out_rows + (size_t)i * cap, h->h_rows + (size_t)i * max_det, (size_t)c * sizeof(mi355_det));
+    }
+    return collect_timing(h, pf, n);
+}
+
+static int create_impl(const uint8_t* blob, size_t nbytes, int device_id, const mi355_opts* opts, mi355_yolo** out) {
+    if (!blob || !out) return fail(MI355_EINVAL, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(MI355_EINVAL, "device_id out of range (no MI355X visible?)");
+    HIPCHK(hipSetDevice(device_id));
+    std::unique_ptr<mi355_yolo> h(new mi355_yolo());
+    h->device = device_id;
+    if (opts && opts->struct_size >= (int)sizeof(mi355_opts) && opts->batch_chunk > 0) h->chunk = opts->batch_chunk;
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
+    const int rc = parse_blob(h.get(), blob, nbytes);
+    if (rc) return rc;
+    *out = h.release();
+    return MI355_OK;
+}
+
+struct DevMem {   // RAII for the one-shot operator entry points
+    std::vector<void*> ptrs;
+    ~DevMem() { for (void* p : ptrs) (void)hipFree(p); }
+    template <class T> hipError_t alloc(T** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 16); if (e == hipSuccess) ptrs.push_back(*p); return e; }
+};
+
+}  // namespace mi355
+
+// ================================================================================================ C ABI
+extern "C" {
+
+const char* mi355_last_error(void) { return g_err.c_str(); }
+
+int mi355_yolo_create_from_memory(const void* blob, size_t nbytes, int device_id, const mi355_opts* opts, mi355_yolo** out) {
+    return create_impl((const uint8_t*)blob, nbytes, device_id, opts, out);
+}
+
+int mi355_yolo_create(const char* path, int device_id, const mi355_opts* opts, mi355_yolo** out) {
+    if (!path || !out) return fail(MI355_EINVAL, "null argument");
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(MI355_EIO, std::string("cannot open weights file: ") + path);
+    std::fseek(f, 0, SEEK_END);
+    const long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> buf(sz > 0 ? (size_t)sz : 0);
+    const size_t got = buf.empty() ? 0 : std::fread(buf.data(), 1, buf.size(), f);
+    std::fclose(f);
+    if (got != buf.size() || buf.empty()) return fail(MI355_EIO, std::string("cannot read weights file: ") + path);
+    return create_impl(buf.data(), buf.size(), device_id, opts, out);
+}
+
+void mi355_yolo_destroy(mi355_yolo* h) { delete h; }
+
+int mi355_yolo_info(const mi355_yolo* h, mi355_model_info* info) {
+    if (!h || !info) return fail(MI355_EINVAL, "null argument");
+    std::memset(info, 0, sizeof(*info));
+    info->task = h->hdr.task; info->nc = h->hdr.nc; info->nkpt = h->hdr.nkpt; info->kdim = h->hdr.kdim;
+    info->reg_max = h->hdr.reg_max; info->n_levels = (int)h->levels.size();
+    for (size_t i = 0; i < h->levels.size(); ++i) info->strides[i] = h->levels[i].stride;
+    info->n_convs = (int)h->convs.size(); info->n_ops = (int)h->ops.size(); info->n_buffers = (int)h->bufs.size();
+    info->n_params = h->n_params; info->macs_640 = h->macs640;
+    std::strncpy(info->family, h->hdr.family == 0 ? "v8" : "v5u", sizeof(info->family) - 1);
+    info->scale = (char)h->hdr.scale;
+    return MI355_OK;
+}
+
+int mi355_yolo_infer(mi355_yolo* h, const uint8_t* bgr, int n, int height, int width, int row_stride, float conf, float iou,
+                     const int* classes, int n_classes, int max_det, int imgsz, mi355_det* out_rows, int cap, int* out_counts) {
+    return infer_impl(h, bgr, false, n, height, width, row_stride, conf, iou, classes, n_classes, max_det, imgsz, out_rows, cap, out_counts);
+}
+
+int mi355_yolo_infer_device(mi355_yolo* h, const uint8_t* bgr_dev, int n, int height, int width, float conf, float iou,
+                            const int* classes, int n_classes, int max_det, int imgsz, mi355_det* out_rows, int cap, int* out_counts) {
+    return infer_impl(h, bgr_dev, true, n, height, width, 0, conf, iou, classes, n_classes, max_det, imgsz, out_rows, cap, out_counts);
+}
+
+int mi355_yolo_set_profiling(mi355_yolo* h, int on) {
+    if (!h) return fail(MI355_EINVAL, "null argument");
+    h->profiling = on != 0;
+    return MI355_OK;
+}
+
+int mi355_yolo_last_timing(const mi355_yolo* h, mi355_timing* t) {
+    if (!h || !t) return fail(MI355_EINVAL, "null argument");
+    *t = h->last;
+    return MI355_OK;
+}
+
+int mi355_yolo_raw_head(mi355_yolo* h, const uint8_t* bgr, int n, int height, int width, int row_stride, int imgsz,
+                        float* out, int* out_channels, int* out_anchors) {
+    if (!h || !out_channels || !out_anchors) return fail(MI355_EINVAL, "null argument");
+    if (n <= 0 || height <= 0 || width <= 0) return fail(MI355_EINVAL, "n, height and width must be positive");
+    if (imgsz <= 0) imgsz = 640;
+    if (imgsz % 32) return fail(MI355_EINVAL, "imgsz must be a multiple of 32");
+    const Geometry g = make_geometry(height, width, imgsz);
+    int A = 0;
+    for (const FileLevel& lv : h->levels) A += (g.Hl / lv.stride) * (g.Wl / lv.stride);
+    *out_channels = h->no(); *out_anchors = A;
+    if (!out) return MI355_OK;
+    if (!bgr) return fail(MI355_EINVAL, "null argument");
+    if (row_stride == 0) row_stride = width * 3;
+    HIPCHK(hipSetDevice(h->device));
+    const int nb = std::min(n, h->chunk);
+    int rc = ensure_shape(h, nb, g.Hl, g.Wl); if (rc) return rc;
+    rc = prepare_geometry(h, g, imgsz); if (rc) return rc;
+    const size_t frame_bytes = (size_t)height * width * 3;
+    if (h->d_in_bytes < frame_bytes * n) {
+        if (h->d_in) (void)hipFree(h->d_in);
+        h->d_in = nullptr; h->d_in_bytes = 0;
+        HIPCHK(hipMalloc(&h->d_in, frame_bytes * n)); h->d_in_bytes = frame_bytes * n;
+    }
+    HIPCHK(hipMemcpy2DAsync(h->d_in, (size_t)width * 3, bgr, (size_t)row_stride, (size_t)width * 3, (size_t)height * n,
+                            hipMemcpyHostToDevice, h->stream));
+    const size_t per = (size_t)A * h->no();
+    if (h->rawhead_floats < per * nb) {
+        if (h->d_rawhead) (void)hipFree(h->d_rawhead); h->d_rawhead = nullptr; h->rawhead_floats = 0;
+        HIPCHK(hipMalloc(&h->d_rawhead, per * nb * 4)); h->rawhead_floats = per * nb;
+    }
+    Prof pf{h};
+    const bool was = h->profiling; h->profiling = false;
+    for (int s = 0; s < n; s += nb) {
+        const int m = std::min(nb, n - s);
+        rc = run_chunk(h, pf, h->d_in + (size_t)s * frame_bytes, m, g);
+        if (rc) { h->profiling = was; return rc; }
+        KCHK(launch_transpose_pred(h->pred, h->d_rawhead, m, A, h->no(), h->stream));
+        HIPCHK(hipMemcpyAsync(out + (size_t)s * per, h->d_rawhead, per * m * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    h->profiling = was;
+    return MI355_OK;
+}
+
+// ------------------------------------------------------------------------------------- single operators
+int mi355_letterbox_shape(int height, int width, int imgsz, int* out_h, int* out_w) {
+    if (!out_h || !out_w || height <= 0 || width <= 0 || imgsz <= 0) return fail(MI355_EINVAL, "bad argument");
+    const Geometry g = make_geometry(height, width, imgsz);
+    *out_h = g.Hl; *out_w = g.Wl;
+    return MI355_OK;
+}
+
+
+int mi355_op_letterbox(int device_id, const uint8_t* bgr, int n, int height, int width, int imgsz, uint8_t* out) {
+    if (!bgr || !out || n <= 0 || height <= 0 || width <= 0 || imgsz <= 0) return fail(MI355_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(device_id));
+    const Geometry g = make_geometry(height, width, imgsz);
+    DevMem dm; uint8_t *d_src, *d_dst; int *d_x, *d_y;
+    std::vector<int> xt, yt;
+    resize_table(g.Wr, g.w0, xt); resize_table(g.Hr, g.h0, yt);
+    const size_t sb = (size_t)n * height * width * 3, db = (size_t)n * g.Hl * g.Wl * 3;
+    HIPCHK(dm.alloc(&d_src, sb)); HIPCHK(dm.alloc(&d_dst, db)); HIPCHK(dm.alloc(&d_x, xt.size() * 4)); HIPCHK(dm.alloc(&d_y, yt.size() * 4));
+    HIPCHK(hipMemcpy(d_src, bgr, sb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_x, xt.data(), xt.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_y, yt.data(), yt.size() * 4, hipMemcpyHostToDevice));
+    LetterboxArgs la{};
+    la.src = d_src; la.H = height; la.W = width; la.frame_stride = (long long)height * width * 3; la.row_stride = width * 3;
+    la.dst = d_dst; la.Hd = g.Hl; la.Wd = g.Wl; la.top = g.top; la.left = g.left; la.Hr = g.Hr; la.Wr = g.Wr;
+    la.xtab = d_x; la.ytab = d_y; la.resize = g.resize ? 1 : 0; la.B = n;
+    KCHK(launch_letterbox(la, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, d_dst, db, hipMemcpyDeviceToHost));
+    return MI355_OK;
+}
+
+int mi355_op_conv2d(int device_id, const float* x, int n, int h, int w, int cin, const float* w_oihw, const float* bias,
+                    int cout, int k, int stride, int silu, const float* residual, float* y) {
+    if (!x || !w_oihw || !bias || !y || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return fail(MI355_EINVAL, "bad argument");
+    if (!((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)))) return fail(MI355_EINVAL, "k/stride not supported");
+    if ((h % stride) || (w % stride)) return fail(MI355_EINVAL, "h and w must be multiples of the stride");
+    HIPCHK(hipSetDevice(device_id));
+    const int ho = h / stride, wo = w / stride;
+    const int cs_in = round_up(cin, 4), cs_out = round_up(cout, 4);
+    const size_t npi = (size_t)n * h * w, npo = (size_t)n * ho * wo;
+    std::vector<float> xin(npi * cs_in, 0.f), yout(npo * cs_out, 0.f), rs;
+    for (size_t p = 0; p < npi; ++p) std::memcpy(&xin[p * cs_in], x + p * cin, (size_t)cin * 4);
+    DevMem dm; float *d_x, *d_y, *d_r = nullptr, *d_w, *d_b;
+    HIPCHK(dm.alloc(&d_x, xin.size() * 4)); HIPCHK(dm.alloc(&d_y, yout.size() * 4));
+    HIPCHK(hipMemcpy(d_x, xin.data(), xin.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d_y, 0, yout.size() * 4));
+    if (residual) {
+        rs.assign(npo * cs_out, 0.f);
+        for (size_t p = 0; p < npo; ++p) std::memcpy(&rs[p * cs_out], residual + p * cout, (size_t)cout * 4);
+        HIPCHK(dm.alloc(&d_r, rs.size() * 4));
+        HIPCHK(hipMemcpy(d_r, rs.data(), rs.size() * 4, hipMemcpyHostToDevice));
+    }
+    std::vector<float> pk(packed_weight_floats(cout, cin, k)), bp(round_up(cout, 16), 0.f);
+    pack_conv_weights(w_oihw, cout, cin, k, pk.data());
+    std::memcpy(bp.data(), bias, (size_t)cout * 4);
+    HIPCHK(dm.alloc(&d_w, pk.size() * 4)); HIPCHK(dm.alloc(&d_b, bp.size() * 4));
+    HIPCHK(hipMemcpy(d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+    ConvArgs a{};
+    a.src = d_x; a.src_cs = cs_in; a.dst = d_y; a.dst_cs = cs_out; a.res = d_r; a.res_cs = cs_out; a.wpk = d_w; a.bias = d_b;
+    a.B = n; a.Hin = h; a.Win = w; a.Hout = ho; a.Wout = wo; a.Cin = cin; a.Cout = cout; a.k = k; a.stride = stride; a.pad = k / 2; a.act = silu ? 1 : 0;
+    ConvLaunch l{};
+    KCHK(plan_conv(a, &l));
+    KCHK(run_conv(l, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(yout.data(), d_y, yout.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < npo; ++p) std::memcpy(y + p * cout, &yout[p * cs_out], (size_t)cout * 4);
+    return MI355_OK;
+}
+
+int mi355_op_stem(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias, int cout,
+                  int k, int stride, float* y) {
+    if (!bgr || !w_oihw || !bias || !y || n <= 0 || h <= 0 || w <= 0 || cout <= 0) return fail(MI355_EINVAL, "bad argument");
+    if ((k != 3 && k != 6) || (h % stride) || (w % stride)) return fail(MI355_EINVAL, "k/stride not supported");
+    HIPCHK(hipSetDevice(device_id));
+    const int ho = h / stride, wo = w / stride, cs = round_up(cout, 4);
+    DevMem dm; uint8_t* d_img; float *d_y, *d_w, *d_b, *d_l;
+    const size_t ib = (size_t)n * h * w * 3, yn = (size_t)n * ho * wo * cs;
+    float lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = (float)i / 255.0f;
+    HIPCHK(dm.alloc(&d_img, ib)); HIPCHK(dm.alloc(&d_y, yn * 4)); HIPCHK(dm.alloc(&d_w, (size_t)cout * 3 * k * k * 4));
+    HIPCHK(dm.alloc(&d_b, (size_t)cout * 4)); HIPCHK(dm.alloc(&d_l, sizeof(lut)));
+    HIPCHK(hipMemcpy(d_img, bgr, ib, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_w, w_oihw, (size_t)cout * 3 * k * k * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_b, bias, (size_t)cout * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_l, lut, sizeof(lut), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d_y, 0, yn * 4));
+    StemArgs s{};
+    s.img = d_img; s.dst = d_y; s.dst_cs = cs; s.w = d_w; s.bias = d_b; s.lut = d_l;
+    s.B = n; s.H = h; s.W = w; s.Hout = ho; s.Wout = wo; s.Cout = cout; s.k = k; s.stride = stride; s.pad = (k == 6 ? 2 : k / 2);
+    KCHK(launch_stem(s, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<float> yo(yn);
+    HIPCHK(hipMemcpy(yo.data(), d_y, yn * 4, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < (size_t)n * ho * wo; ++p) std::memcpy(y + p * cout, &yo[p * cs], (size_t)cout * 4);
+    return MI355_OK;
+}
+
+int mi355_op_nms(int device_id, const float* pred, int n, int nc, int extra, int anchors, float conf, float iou,
+                 const int* classes, int n_classes, int max_det, mi355_det* out_rows, int cap, int* out_counts) {
+    if (!pred || !out_rows || !out_counts || n <= 0 || nc <= 0 || extra < 0 || anchors <= 0 || cap < 1) return fail(MI355_EINVAL, "bad argument");
+    if (max_det <= 0) max_det = 300;
+    if (max_det > 1024) return fail(MI355_EINVAL, "max_det must be <= 1024");
+    if (extra > MI355_MAX_KPT_FLOATS) return fail(MI355_EINVAL, "too many extra columns");
+    HIPCHK(hipSetDevice(device_id));
+    const int no = 4 + nc + extra;
+    int ap2 = 1; while (ap2 < anchors) ap2 <<= 1;
+    DevMem dm; float *d_in, *d_am; float2* d_best; unsigned long long* d_keys; mi355_det* d_rows; int* d_counts; unsigned* d_mask = nullptr;
+    const size_t pn = (size_t)n * no * anchors;
+    HIPCHK(dm.alloc(&d_in, pn * 4)); HIPCHK(dm.alloc(&d_am, pn * 4)); HIPCHK(dm.alloc(&d_best, (size_t)n * anchors * sizeof(float2)));
+    HIPCHK(dm.alloc(&d_keys, (size_t)n * ap2 * 8)); HIPCHK(dm.alloc(&d_rows, (size_t)n * max_det * sizeof(mi355_det)));
+    HIPCHK(dm.alloc(&d_counts, (size_t)2 * n * sizeof(int)));
+    HIPCHK(hipMemcpy(d_in, pred, pn * 4, hipMemcpyHostToDevice));
+    if (n_classes > 0 && classes) {
+        std::vector<unsigned> m((nc + 31) / 32, 0u);
+        for (int i = 0; i < n_classes; ++i) if (classes[i] >= 0 && classes[i] < nc) m[classes[i] >> 5] |= 1u << (classes[i] & 31);
+        HIPCHK(dm.alloc(&d_mask, m.size() * 4));
+        HIPCHK(hipMemcpy(d_mask, m.data(), m.size() * 4, hipMemcpyHostToDevice));
+    }
+    KCHK(launch_transpose_pred(d_in, d_am, n, no, anchors, nullptr));      // [n][no][A] -> [n][A][no]
+    KCHK(launch_best_from_pred(d_am, n, anchors, no, nc, d_best, nullptr));
+    NmsArgs na{};
+    na.pred = d_am; na.best = d_best; na.B = n; na.A = anchors; na.no = no; na.nc = nc; na.nk = extra; na.kdim = 0;
+    na.conf = conf; na.iou = iou; na.max_det = max_det; na.max_nms = 30000; na.max_wh = 7680.f;
+    na.class_mask = d_mask; na.keys = d_keys; na.Apow2 = ap2; na.scale_back = 0; na.gain = 1.f;
+    na.out_rows = d_rows; na.out_counts = d_counts;
+    KCHK(launch_nms(na, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<mi355_det> rows((size_t)n * max_det);
+    std::vector<int> counts(n);
+    HIPCHK(hipMemcpy(rows.data(), d_rows, rows.size() * sizeof(mi355_det), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(counts.data(), d_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        const int c = std::min(counts[i], cap);
+        out_counts[i] = c;
+        std::memcpy(out_rows + (size_t)i * cap, rows.data() + (size_t)i * max_det, (size_t)c * sizeof(mi355_det));
+    }
+    return MI355_OK;
+}
+
+}  // extern "C"

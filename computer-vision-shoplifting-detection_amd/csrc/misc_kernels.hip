@@ -1,0 +1,199 @@
+// Bandwidth-bound kernels around the conv stack: the u8 stem conv, nearest 2x upsample, the SPPF max-pools
+// and the letterbox resize/pad.  All NHWC, 16-byte accesses per lane wherever the layout allows.
+#include "common.h"
+
+namespace mi355 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float silu_m(float v) { return v / (1.0f + expf(-v)); }
+
+// ---------------------------------------------------------------------------------------------- stem
+// model.0: Conv(3 -> Cout, k, s) on the letterboxed uint8 BGR frame.  Fuses the rest of
+// engine/predictor.py:preprocess (BGR->RGB, uint8 -> float32, /255 via an exact 256-entry table) into the
+// conv read, so the 4.9 MB/frame fp32 input tensor never exists.  One lane = one output pixel x 4 couts
+// (16-byte store); the Cout/4 lanes of a pixel sit next to each other so a wave writes contiguous memory.
+// Direct conv on the vector ALUs: K = 27 (or 108) is far too shallow for the matrix pipe and the layer is
+// HBM-write bound (16-48 floats out per 27 bytes in).
+template <int KS>
+__global__ __launch_bounds__(256) void stem_conv_u8(StemArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [KS*KS*3][Cout4] then lut[256]
+    const int cq = (a.Cout + 3) >> 2, cout4 = cq << 2;
+    float* lut = wl + KS * KS * 3 * cout4;
+    for (int i = threadIdx.x; i < KS * KS * 3 * cout4; i += blockDim.x) {
+        const int co = i % cout4, r = i / cout4;       // r = tap*3 + byte channel (B,G,R)
+        const int cb = r % 3, tap = r / 3;
+        // byte channel cb (0=B,1=G,2=R) feeds model channel 2-cb (im[..., ::-1])
+        wl[i] = co < a.Cout ? a.w[((size_t)co * 3 + (2 - cb)) * (KS * KS) + tap] : 0.f;
+    }
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) lut[i] = a.lut[i];
+    __syncthreads();
+    const int ppb = blockDim.x / cq;                   // pixels per block
+    const int q = threadIdx.x % cq, lp = threadIdx.x / cq;
+    if (lp >= ppb) return;
+    const long total = (long)a.B * a.Hout * a.Wout;
+    const long pix = (long)blockIdx.x * ppb + lp;
+    if (pix >= total) return;
+    const int ox = (int)(pix % a.Wout);
+    const int oy = (int)((pix / a.Wout) % a.Hout);
+    const int b = (int)(pix / ((long)a.Wout * a.Hout));
+    const uint8_t* img = a.img + (size_t)b * a.H * a.W * 3;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < KS; ++kh) {
+        const int y = oy * a.stride - a.pad + kh;
+        if ((unsigned)y >= (unsigned)a.H) continue;
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+            const int x = ox * a.stride - a.pad + kw;
+            if ((unsigned)x >= (unsigned)a.W) continue;
+            const uint8_t* px = img + ((size_t)y * a.W + x) * 3;
+            const float* wr = wl + ((kh * KS + kw) * 3) * cout4 + 4 * q;
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                const float v = lut[px[cb]];
+                const f32x4 w4 = *(const f32x4*)(wr + cb * cout4);
+                acc += v * w4;
+            }
+        }
+    }
+    const int c = 4 * q;
+    float* d = a.dst + (size_t)pix * a.dst_cs + c;
+    for (int i = 0; i < 4 && c + i < a.Cout; ++i) d[i] = silu_m(acc[i] + a.bias[c + i]);
+}
+
+const char* launch_stem(const StemArgs& a, hipStream_t st) {
+    if (a.k != 3 && a.k != 6) return "stem: only 3x3 and 6x6 stems are supported";
+    const int cq = (a.Cout + 3) / 4;
+    if (cq > 256) return "stem: too many output channels";
+    const int ppb = 256 / cq;
+    const long total = (long)a.B * a.Hout * a.Wout;
+    const unsigned grid = (unsigned)((total + ppb - 1) / ppb);
+    const size_t lds = ((size_t)a.k * a.k * 3 * cq * 4 + 256) * sizeof(float);
+    if (a.k == 3) hipLaunchKernelGGL(stem_conv_u8<3>, dim3(grid), dim3(256), lds, st, a);
+    else          hipLaunchKernelGGL(stem_conv_u8<6>, dim3(grid), dim3(256), lds, st, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// ---------------------------------------------------------------------------------------------- upsample
+// torch.nn.Upsample(scale_factor=2, mode="nearest") written straight into the concat buffer's channel slice.
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* src, int src_cs, float* dst, int dst_cs,
+                                                         int B, int H, int W, int c4n, int C) {
+    const long total = (long)B * (2 * H) * (2 * W) * c4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % c4n);
+        long p = i / c4n;
+        const int ox = (int)(p % (2 * W)); p /= (2 * W);
+        const int oy = (int)(p % (2 * H));
+        const int b = (int)(p / (2 * H));
+        const float* s = src + (((size_t)b * H + (oy >> 1)) * W + (ox >> 1)) * src_cs + 4 * q;
+        float* d = dst + (((size_t)b * 2 * H + oy) * (2 * W) + ox) * dst_cs + 4 * q;
+        if (4 * q + 3 < C) *(f32x4*)d = *(const f32x4*)s;
+        else for (int j = 0; 4 * q + j < C; ++j) d[j] = s[j];
+    }
+}
+
+const char* launch_upsample2x(const float* src, int src_cs, float* dst, int dst_cs, int B, int H, int W, int C,
+                              hipStream_t st) {
+    const int c4n = (C + 3) / 4;
+    const long total = (long)B * 4 * H * W * c4n;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid), dim3(256), 0, st, src, src_cs, dst, dst_cs, B, H, W, c4n, C);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// ---------------------------------------------------------------------------------------------- SPPF pools
+// Three chained MaxPool2d(5, stride 1, pad 2) (block.py:SPPF.forward).  max is exact and pooling with -inf
+// padding composes, so x2 = maxpool9(x0) and x3 = maxpool13(x0): all three are produced from one pass over
+// the 13x13 neighbourhood of x0 (L1/L2-resident: the map is H/32 x W/32).
+__global__ __launch_bounds__(256) void sppf_pools_kernel(const float* src, int src_cs, float* dst, int dst_cs,
+                                                         int B, int H, int W, int c4n, int C) {
+    const long total = (long)B * H * W * c4n;
+    const float NEG = -__builtin_huge_valf();
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % c4n);
+        long p = i / c4n;
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H);
+        const int b = (int)(p / H);
+        f32x4 m1 = (f32x4){NEG, NEG, NEG, NEG}, m2 = m1, m3 = m1;
+        for (int dy = -6; dy <= 6; ++dy) {
+            const int yy = y + dy;
+            if ((unsigned)yy >= (unsigned)H) continue;
+            const int ady = dy < 0 ? -dy : dy;
+            for (int dx = -6; dx <= 6; ++dx) {
+                const int xx = x + dx;
+                if ((unsigned)xx >= (unsigned)W) continue;
+                const int adx = dx < 0 ? -dx : dx;
+                const int r = ady > adx ? ady : adx;
+                const f32x4 v = *(const f32x4*)(src + (((size_t)b * H + yy) * W + xx) * src_cs + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    m3[j] = fmaxf(m3[j], v[j]);
+                    if (r <= 4) m2[j] = fmaxf(m2[j], v[j]);
+                    if (r <= 2) m1[j] = fmaxf(m1[j], v[j]);
+                }
+            }
+        }
+        float* d = dst + (((size_t)b * H + y) * W + x) * dst_cs + 4 * q;
+        for (int j = 0; j < 4 && 4 * q + j < C; ++j) { d[j] = m1[j]; d[C + j] = m2[j]; d[2 * C + j] = m3[j]; }
+    }
+}
+
+const char* launch_sppf_pools(const float* src, int src_cs, float* dst, int dst_cs, int B, int H, int W, int C,
+                              hipStream_t st) {
+    if (C & 3) return "sppf: channel count must be a multiple of 4";
+    const int c4n = C / 4;
+    const long total = (long)B * H * W * c4n;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(sppf_pools_kernel, dim3(grid), dim3(256), 0, st, src, src_cs, dst, dst_cs, B, H, W, c4n, C);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// ---------------------------------------------------------------------------------------------- letterbox
+// data/augment.py:LetterBox: cv2.resize(INTER_LINEAR) in OpenCV's 11-bit fixed point, then a 114 border.
+// Integer arithmetic only -> bit-exact against the oracle's restatement.
+__global__ __launch_bounds__(256) void letterbox_kernel(LetterboxArgs a) {
+    const long total = (long)a.B * a.Hd * a.Wd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % a.Wd);
+        const int y = (int)((i / a.Wd) % a.Hd);
+        const int b = (int)(i / ((long)a.Wd * a.Hd));
+        uint8_t* d = a.dst + (size_t)i * 3;
+        const int rx = x - a.left, ry = y - a.top;
+        if ((unsigned)rx >= (unsigned)a.Wr || (unsigned)ry >= (unsigned)a.Hr) { d[0] = d[1] = d[2] = 114; continue; }
+        const uint8_t* s = a.src + (size_t)b * a.frame_stride;
+        if (!a.resize) {
+            const uint8_t* p = s + (size_t)ry * a.row_stride + (size_t)rx * 3;
+            d[0] = p[0]; d[1] = p[1]; d[2] = p[2];
+            continue;
+        }
+        const int x0 = a.xtab[rx * 3], ax0 = a.xtab[rx * 3 + 1], ax1 = a.xtab[rx * 3 + 2];
+        const int y0 = a.ytab[ry * 3], by0 = a.ytab[ry * 3 + 1], by1 = a.ytab[ry * 3 + 2];
+        const int x1 = x0 + 1 < a.W ? x0 + 1 : a.W - 1;
+        const int y1 = y0 + 1 < a.H ? y0 + 1 : a.H - 1;
+        const uint8_t* r0 = s + (size_t)y0 * a.row_stride;
+        const uint8_t* r1 = s + (size_t)y1 * a.row_stride;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int s0 = r0[x0 * 3 + c] * ax0 + r0[x1 * 3 + c] * ax1;
+            const int s1 = r1[x0 * 3 + c] * ax0 + r1[x1 * 3 + c] * ax1;
+            int v = (((by0 * (s0 >> 4)) >> 16) + ((by1 * (s1 >> 4)) >> 16) + 2) >> 2;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            d[c] = (uint8_t)v;
+        }
+    }
+}
+
+const char* launch_letterbox(const LetterboxArgs& a, hipStream_t st) {
+    const long total = (long)a.B * a.Hd * a.Wd;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(letterbox_kernel, dim3(grid), dim3(256), 0, st, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+}  // namespace mi355

@@ -1,0 +1,275 @@
+// Head decode (DFL + dist2bbox + sigmoid + keypoint decode) and non_max_suppression + scale-back.
+//
+// Restates, in the reference's own fp32 operation order (FP contraction is switched OFF in this file):
+//   ultralytics/nn/modules/head.py:Detect._inference / Pose.kpts_decode, block.py:DFL, utils/tal.py:dist2bbox
+//   ultralytics/utils/nms.py:non_max_suppression (+ torchvision.ops.nms CPU kernel: stable descending sort,
+//   suppress IoU > thr, IoU = inter / (area_i + area_j - inter))
+//   ultralytics/utils/ops.py:scale_boxes / clip_boxes / scale_coords / clip_coords
+// reached from /root/reference/model.py:38-40.
+#include "common.h"
+#include "../../include/mi355_yolo.h"
+
+#pragma clang fp contract(off)
+
+namespace mi355 {
+
+// ---------------------------------------------------------------------------------------------- decode
+// One lane per anchor.  Reads the raw head maps (NHWC, per level: 64 box logits | nc class logits | nk kpts)
+// and writes the decoded prediction row [4 + nc + nk] (anchor-major) plus (best score, best class).
+__global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
+    const long total = (long)a.B * a.A;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int an = (int)(i % a.A), b = (int)(i / a.A);
+    int l = 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        if (j < a.n_levels && an >= a.lv[j].anchor0) l = j;
+    const HeadLevelArgs lv = a.lv[l];
+    const int li = an - lv.anchor0;
+    const int y = li / lv.W, x = li - y * lv.W;
+    const float* p = lv.buf + (((size_t)b * lv.H + y) * lv.W + x) * lv.cs;
+    const float ax = (float)x + 0.5f, ay = (float)y + 0.5f, st = (float)lv.stride;
+    const int nk = a.nkpt * a.kdim, no = 4 + a.nc + nk;
+    float* out = a.pred + (size_t)i * no;
+
+    float dist[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float4* q = (const float4*)(p + lv.box_off + 16 * s);
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float4 t = q[j]; v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w; }
+        float m = v[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) m = fmaxf(m, v[j]);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { v[j] = expf(v[j] - m); sum += v[j]; }
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) d += (v[j] / sum) * (float)j;
+        dist[s] = d;
+    }
+    const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
+    out[0] = ((x1 + x2) / 2.0f) * st;
+    out[1] = ((y1 + y2) / 2.0f) * st;
+    out[2] = (x2 - x1) * st;
+    out[3] = (y2 - y1) * st;
+    float best = -1.f; int bi = 0;
+    for (int c = 0; c < a.nc; ++c) {
+        const float s = 1.0f / (1.0f + expf(-p[lv.cls_off + c]));
+        out[4 + c] = s;
+        if (s > best) { best = s; bi = c; }
+    }
+    a.best[i] = make_float2(best, (float)bi);
+    for (int k = 0; k < a.nkpt; ++k) {
+        const float* kp = p + lv.kpt_off + k * a.kdim;
+        float* ko = out + 4 + a.nc + k * a.kdim;
+        ko[0] = (kp[0] * 2.0f + (ax - 0.5f)) * st;
+        ko[1] = (kp[1] * 2.0f + (ay - 0.5f)) * st;
+        if (a.kdim == 3) ko[2] = 1.0f / (1.0f + expf(-kp[2]));
+    }
+}
+
+const char* launch_decode(const DecodeArgs& a, hipStream_t st) {
+    const long total = (long)a.B * a.A;
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// [B][rows][cols] -> [B][cols][rows]  (Ultralytics [B, no, A] <-> anchor-major [B, A, no])
+__global__ void transpose_kernel(const float* in, float* out, int B, int rows, int cols) {
+    const long total = (long)B * rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cols);
+        const int r = (int)((i / cols) % rows);
+        const int b = (int)(i / ((long)cols * rows));
+        out[((size_t)b * cols + c) * rows + r] = in[i];
+    }
+}
+const char* launch_transpose_pred(const float* in, float* out, int B, int rows, int cols, hipStream_t st) {
+    const long total = (long)B * rows * cols;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(transpose_kernel, dim3(grid), dim3(256), 0, st, in, out, B, rows, cols);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+__global__ void best_kernel(const float* pred, int B, int A, int no, int nc, float2* best) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * A) return;
+    const float* p = pred + (size_t)i * no + 4;
+    float bs = -1.f; int bi = 0;
+    for (int c = 0; c < nc; ++c) if (p[c] > bs) { bs = p[c]; bi = c; }
+    best[i] = make_float2(bs, (float)bi);
+}
+const char* launch_best_from_pred(const float* pred, int B, int A, int no, int nc, float2* best, hipStream_t st) {
+    const long total = (long)B * A;
+    hipLaunchKernelGGL(best_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pred, B, A, no, nc, best);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// ---------------------------------------------------------------------------------------------- NMS
+// Kernel 1 (one 256-thread block per image): candidate filter (best score > conf, best class allowed),
+// then a bitonic sort of the 64-bit keys (~score_bits << 32 | anchor): ascending key order == descending
+// score with ties broken by ascending anchor index == torch's stable descending sort of the anchor-ordered
+// candidate list.
+__device__ void bitonic_sort(unsigned long long* v, int n2, int tid, int nthreads) {
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += nthreads) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = v[i], b = v[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { v[i] = b; v[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+constexpr int NMS_LDS_KEYS = 4096;
+
+__global__ __launch_bounds__(256) void nms_sort_kernel(NmsArgs a, int* cand_counts) {
+    __shared__ unsigned long long skeys[NMS_LDS_KEYS];
+    __shared__ int scount;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    unsigned long long* keys = a.keys + (size_t)b * a.Apow2;
+    if (tid == 0) scount = 0;
+    __syncthreads();
+    const float2* best = a.best + (size_t)b * a.A;
+    for (int an = tid; an < a.A; an += 256) {
+        const float2 bc = best[an];
+        bool ok = bc.x > a.conf;
+        if (ok && a.class_mask) { const int c = (int)bc.y; ok = (a.class_mask[c >> 5] >> (c & 31)) & 1u; }
+        if (ok) {
+            const int pos = atomicAdd(&scount, 1);
+            keys[pos] = ((unsigned long long)(~__float_as_uint(bc.x)) << 32) | (unsigned)an;
+        }
+    }
+    __syncthreads();
+    const int n = scount;
+    int n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    for (int i = n + tid; i < n2; i += 256) keys[i] = ~0ull;
+    __syncthreads();
+    if (n2 > 1) {
+        if (n2 <= NMS_LDS_KEYS) {
+            for (int i = tid; i < n2; i += 256) skeys[i] = keys[i];
+            __syncthreads();
+            bitonic_sort(skeys, n2, tid, 256);
+            for (int i = tid; i < n; i += 256) keys[i] = skeys[i];
+        } else {
+            bitonic_sort(keys, n2, tid, 256);
+        }
+    }
+    if (tid == 0) cand_counts[b] = n < a.max_nms ? n : a.max_nms;     // "if n > max_nms: keep the top max_nms by conf"
+}
+
+// Kernel 2 (one wave per image): greedy suppression over the sorted candidates in chunks of 64, stopping at
+// max_det kept boxes, then scale-back and row packing.
+constexpr int NMS_MAX_DET = 1024;
+
+struct CandBox { float x1, y1, x2, y2, area; };
+
+__device__ __forceinline__ bool iou_gt(const CandBox& i, const CandBox& j, float thr) {
+    const float xx1 = fmaxf(i.x1, j.x1), yy1 = fmaxf(i.y1, j.y1);
+    const float xx2 = fminf(i.x2, j.x2), yy2 = fminf(i.y2, j.y2);
+    const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+    const float inter = w * h;
+    const float ovr = inter / (i.area + j.area - inter);
+    return ovr > thr;
+}
+
+__global__ __launch_bounds__(64) void nms_greedy_kernel(NmsArgs a, const int* cand_counts) {
+    __shared__ float kx1[NMS_MAX_DET], ky1[NMS_MAX_DET], kx2[NMS_MAX_DET], ky2[NMS_MAX_DET], kar[NMS_MAX_DET];
+    __shared__ int kan[NMS_MAX_DET];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const unsigned long long* keys = a.keys + (size_t)b * a.Apow2;
+    const float* pred = a.pred + (size_t)b * a.A * a.no;
+    const float2* best = a.best + (size_t)b * a.A;
+    const int n = cand_counts[b];
+    int nk = 0;
+    for (int base = 0; base < n && nk < a.max_det; base += 64) {
+        const int j = base + lane;
+        const bool valid = j < n;
+        int an = 0;
+        CandBox me = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            an = (int)(keys[j] & 0xffffffffull);
+            const float* p = pred + (size_t)an * a.no;
+            // xywh2xyxy, then boxes = x[:, :4] + cls * max_wh
+            const float hw = p[2] / 2.0f, hh = p[3] / 2.0f;
+            const float c = best[an].y * a.max_wh;
+            me.x1 = (p[0] - hw) + c; me.y1 = (p[1] - hh) + c;
+            me.x2 = (p[0] + hw) + c; me.y2 = (p[1] + hh) + c;
+            me.area = (me.x2 - me.x1) * (me.y2 - me.y1);
+        }
+        bool alive = valid;
+        for (int k = 0; k < nk; ++k) {
+            const CandBox kb = {kx1[k], ky1[k], kx2[k], ky2[k], kar[k]};
+            if (alive && iou_gt(kb, me, a.iou)) alive = false;
+        }
+        unsigned long long mask = __ballot(alive);
+        while (mask) {
+            const int jj = __ffsll((long long)mask) - 1;
+            CandBox kb;
+            kb.x1 = __shfl(me.x1, jj); kb.y1 = __shfl(me.y1, jj); kb.x2 = __shfl(me.x2, jj); kb.y2 = __shfl(me.y2, jj);
+            kb.area = __shfl(me.area, jj);
+            if (lane == jj) { kx1[nk] = me.x1; ky1[nk] = me.y1; kx2[nk] = me.x2; ky2[nk] = me.y2; kar[nk] = me.area; kan[nk] = an; }
+            ++nk;
+            if (nk >= a.max_det) break;
+            if (alive && lane > jj && iou_gt(kb, me, a.iou)) alive = false;
+            mask = __ballot(alive && lane > jj);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (lane == 0) a.out_counts[b] = nk;
+    mi355_det* rows = (mi355_det*)a.out_rows + (size_t)b * a.max_det;
+    for (int k = lane; k < nk; k += 64) {
+        const int an = kan[k];
+        const float* p = pred + (size_t)an * a.no;
+        const float hw = p[2] / 2.0f, hh = p[3] / 2.0f;
+        float x1 = p[0] - hw, y1 = p[1] - hh, x2 = p[0] + hw, y2 = p[1] + hh;
+        if (a.scale_back) {
+            x1 -= a.pad_x; y1 -= a.pad_y; x2 -= a.pad_x; y2 -= a.pad_y;
+            x1 /= a.gain; y1 /= a.gain; x2 /= a.gain; y2 /= a.gain;
+            x1 = fminf(fmaxf(x1, 0.f), a.orig_w); y1 = fminf(fmaxf(y1, 0.f), a.orig_h);
+            x2 = fminf(fmaxf(x2, 0.f), a.orig_w); y2 = fminf(fmaxf(y2, 0.f), a.orig_h);
+        }
+        mi355_det& r = rows[k];
+        r.x1 = x1; r.y1 = y1; r.x2 = x2; r.y2 = y2;
+        r.conf = best[an].x; r.cls = (int)best[an].y; r.anchor_idx = an;
+        const int nkf = a.nk < MI355_MAX_KPT_FLOATS ? a.nk : MI355_MAX_KPT_FLOATS;
+        const float* kp = p + 4 + a.nc;
+        const int kd = a.kdim > 0 ? a.kdim : 1;
+        for (int q = 0; q < nkf; ++q) {
+            float v = kp[q];
+            if (a.scale_back && (q % kd) < 2) {
+                const bool isx = (q % kd) == 0;
+                v -= isx ? a.kpad_x : a.kpad_y;
+                v /= a.gain;
+                v = fminf(fmaxf(v, 0.f), isx ? a.orig_w : a.orig_h);
+            }
+            r.kpt[q] = v;
+        }
+        for (int q = nkf; q < MI355_MAX_KPT_FLOATS; ++q) r.kpt[q] = 0.f;
+    }
+}
+
+const char* launch_nms(const NmsArgs& a, hipStream_t st) {
+    if (a.max_det < 1 || a.max_det > NMS_MAX_DET) return "nms: max_det must be in [1, 1024]";
+    // cand_counts lives in the tail of out_counts' allocation: out_counts[B .. 2B)
+    int* cand_counts = a.out_counts + a.B;
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(a.B), dim3(256), 0, st, a, cand_counts);
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(a.B), dim3(64), 0, st, a, cand_counts);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+}  // namespace mi355

@@ -1,0 +1,233 @@
+"""``YOLO`` facade over libmi355yolo.so with the call surface the reference uses.
+
+Drop-in for ``from ultralytics import YOLO`` on the reference's hot path
+(``/root/reference/model.py:5,18,38-40``): ``YOLO(path)``, ``model(frame, conf=, iou=, classes=,
+max_det=, imgsz=)``, ``model.predict(...)`` and ``model.track(...)`` return ``list[Results]`` whose
+``.boxes`` / ``.keypoints`` behave like Ultralytics' (results.py).  All per-frame arithmetic runs in the
+HIP engine through the C ABI (include/mi355_yolo.h); nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .results import Results
+from .weights import build_from_state_dict, from_bytes
+
+COCO_NAMES = ["person", "bicycle", "car", "motorcycle", "airplane", "bus", "train", "truck", "boat", "traffic light",
+              "fire hydrant", "stop sign", "parking meter", "bench", "bird", "cat", "dog", "horse", "sheep", "cow",
+              "elephant", "bear", "zebra", "giraffe", "backpack", "umbrella", "handbag", "tie", "suitcase", "frisbee",
+              "skis", "snowboard", "sports ball", "kite", "baseball bat", "baseball glove", "skateboard", "surfboard",
+              "tennis racket", "bottle", "wine glass", "cup", "fork", "knife", "spoon", "bowl", "banana", "apple",
+              "sandwich", "orange", "broccoli", "carrot", "hot dog", "pizza", "donut", "cake", "chair", "couch",
+              "potted plant", "bed", "dining table", "toilet", "tv", "laptop", "mouse", "remote", "keyboard",
+              "cell phone", "microwave", "oven", "toaster", "sink", "refrigerator", "book", "clock", "vase", "scissors",
+              "teddy bear", "hair drier", "toothbrush"]
+
+
+def default_names(nc: int) -> Dict[int, str]:
+    if nc == 80:
+        return dict(enumerate(COCO_NAMES))
+    if nc == 1:
+        return {0: "person"}
+    return {i: f"class{i}" for i in range(nc)}
+
+
+class YOLO:
+    """MI355X-native stand-in for ``ultralytics.YOLO`` (detect and pose tasks).
+
+    ``model`` may be a ``.mi355w`` path, a ``.pt`` Ultralytics checkpoint (converted on the fly by
+    ``cvsd_amd.convert``), or the raw bytes of a ``.mi355w`` image (e.g. received by broadcast).
+    """
+
+    def __init__(self, model: Union[str, bytes, os.PathLike], task: Optional[str] = None, device: int = 0,
+                 batch_chunk: int = 0, verbose: bool = False):
+        lib = _lib.lib()
+        self._lock = threading.Lock()          # Ultralytics serialises predict() with a per-predictor lock
+        self._h = C.c_void_p()
+        self.device = int(device)
+        opts = _lib.Opts(struct_size=C.sizeof(_lib.Opts), batch_chunk=int(batch_chunk))
+        if isinstance(model, (bytes, bytearray, memoryview)):
+            blob = bytes(model)
+            self.ckpt_path = None
+        else:
+            path = os.fspath(model)
+            self.ckpt_path = path
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"weights file not found: {path!r} (no network: nothing is downloaded)")
+            if path.endswith(".pt"):
+                from .convert import convert_pt
+                blob = convert_pt(path)
+            else:
+                with open(path, "rb") as f:
+                    blob = f.read()
+        self._blob_meta = from_bytes(blob)[2] if blob[:8] == b"MI355YW1" else {}
+        _lib.check(lib.mi355_yolo_create_from_memory(blob, len(blob), self.device, C.byref(opts), C.byref(self._h)))
+        info = _lib.ModelInfo()
+        _lib.check(lib.mi355_yolo_info(self._h, C.byref(info)))
+        self.info_struct = info
+        self.task = "pose" if info.task == 1 else "detect"
+        if task is not None and task != self.task:
+            raise ValueError(f"checkpoint is a {self.task!r} model, not {task!r}")
+        self.nc = info.nc
+        self.kpt_shape = (info.nkpt, info.kdim)
+        names = self._blob_meta.get("names")
+        self.names = {int(k): v for k, v in names.items()} if names else default_names(self.nc)
+        self._tracker = None
+
+    # ------------------------------------------------------------------------------------------ construction
+    @classmethod
+    def from_state_dict(cls, name: str, state_dict: Dict[str, np.ndarray], nc: Optional[int] = None, **kw) -> "YOLO":
+        """Build from an unfused Ultralytics-named state dict (what a ``.pt`` holds) for model ``name``."""
+        return cls(build_from_state_dict(name, state_dict, nc=nc), **kw)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _lib.lib().mi355_yolo_destroy(h)
+            except Exception:
+                pass
+            self._h = C.c_void_p()
+
+    def info(self, detailed: bool = False, verbose: bool = False):
+        i = self.info_struct
+        return i.n_convs, int(i.n_params), 0, 2.0 * i.macs_640 / 1e9     # (layers, params, gradients, GFLOPs)
+
+    # ------------------------------------------------------------------------------------------ inference
+    @staticmethod
+    def _as_batch(source):
+        """-> (array-or-tensor [N,H,W,3] uint8, list of originals or None)"""
+        if isinstance(source, torch.Tensor):
+            if source.dtype != torch.uint8 or source.ndim != 4 or source.shape[-1] != 3:
+                raise ValueError("tensor sources must be uint8 [N,H,W,3] BGR frames")
+            return source.contiguous(), None
+        if isinstance(source, np.ndarray):
+            if source.ndim == 3:
+                source = source[None]
+            if source.dtype != np.uint8 or source.ndim != 4 or source.shape[-1] != 3:
+                raise ValueError("frames must be uint8 arrays of shape [H,W,3] (BGR, as cv2 delivers them)")
+            return np.ascontiguousarray(source), list(source)
+        if isinstance(source, (list, tuple)):
+            if not source:
+                raise ValueError("empty source")
+            shapes = {tuple(np.shape(f)) for f in source}
+            if len(shapes) != 1:
+                raise ValueError("frames of different shapes in one call are not supported; call once per shape")
+            arr = np.ascontiguousarray(np.stack([np.asarray(f) for f in source]))
+            return YOLO._as_batch(arr)[0], list(source)
+        raise TypeError(f"unsupported source type {type(source).__name__}: pass decoded BGR uint8 frames "
+                        f"(frame decode stays on the host, as in the reference's cv2.VideoCapture loop)")
+
+    def _infer_rows(self, batch, conf, iou, classes, max_det, imgsz):
+        lib = _lib.lib()
+        n, h, w = int(batch.shape[0]), int(batch.shape[1]), int(batch.shape[2])
+        rows = np.zeros((n, max_det, _lib.DET_WORDS), dtype=np.float32)
+        counts = np.zeros(n, dtype=np.int32)
+        cls_arr = None
+        ncls = 0
+        if classes is not None:
+            cl = [int(classes)] if np.isscalar(classes) else [int(c) for c in classes]
+            cls_arr = (C.c_int * len(cl))(*cl)
+            ncls = len(cl)
+        cp = counts.ctypes.data_as(C.POINTER(C.c_int))
+        with self._lock:
+            if isinstance(batch, torch.Tensor):
+                if not batch.is_cuda:
+                    batch = batch.numpy()
+                else:
+                    if batch.device.index != self.device:
+                        raise ValueError("frames live on a different GPU than the engine")
+                    torch.cuda.current_stream(batch.device).synchronize()   # engine runs on its own stream
+                    _lib.check(lib.mi355_yolo_infer_device(self._h, batch.data_ptr(), n, h, w, conf, iou, cls_arr, ncls,
+                                                           max_det, imgsz, rows.ctypes.data, max_det, cp))
+                    return rows, counts, (h, w)
+            _lib.check(lib.mi355_yolo_infer(self._h, batch.ctypes.data, n, h, w, 0, conf, iou, cls_arr, ncls, max_det,
+                                            imgsz, rows.ctypes.data, max_det, cp))
+        return rows, counts, (h, w)
+
+    def predict(self, source=None, conf: Optional[float] = None, iou: float = 0.7, classes=None, max_det: int = 300,
+                imgsz: int = 640, half: bool = False, verbose: bool = False, stream: bool = False, **kwargs
+                ) -> List[Results]:
+        """``model.predict`` / ``model(...)``: ultralytics/engine/model.py:Model.predict."""
+        if half:
+            raise NotImplementedError("half=True: this engine computes in fp32 (the reference's CPU path dtype)")
+        if isinstance(imgsz, (list, tuple)):
+            imgsz = int(max(imgsz))
+        conf = 0.25 if conf is None else float(conf)
+        batch, originals = self._as_batch(source)
+        rows, counts, shape = self._infer_rows(batch, conf, float(iou), classes, int(max_det), int(imgsz))
+        t = _lib.Timing()
+        _lib.lib().mi355_yolo_last_timing(self._h, C.byref(t))
+        per_img_ms = t.total_ms / max(1, int(batch.shape[0]))
+        out = []
+        for i in range(len(counts)):
+            r = rows[i, :counts[i]]
+            ints = r[:, 5:7].view(np.int32)
+            data = np.concatenate([r[:, :5], ints[:, :1].astype(np.float32)], axis=1)       # x1,y1,x2,y2,conf,cls
+            kp = None
+            if self.task == "pose":
+                nk = self.kpt_shape[0] * self.kpt_shape[1]
+                kp = torch.from_numpy(r[:, 7:7 + nk].reshape(len(r), *self.kpt_shape).copy())
+            out.append(Results(originals[i] if originals is not None else None, f"image{i}.jpg", self.names,
+                               boxes=torch.from_numpy(data), keypoints=kp, orig_shape=shape,
+                               speed={"preprocess": 0.0, "inference": per_img_ms, "postprocess": 0.0},
+                               anchor_idx=ints[:, 1].copy()))
+        return out
+
+    __call__ = predict
+
+    def track(self, source=None, persist: bool = False, show: bool = False, conf: Optional[float] = None, **kwargs
+              ) -> List[Results]:
+        """``model.track`` (``/root/reference/model.py:38``): predict at conf 0.1, then the tracker callback adds
+        ids.  ultralytics/engine/model.py:Model.track forces batch 1; frames are handled one at a time, in order."""
+        from .tracker import BYTETracker
+        kwargs.pop("batch", None)
+        conf = 0.1 if conf is None else conf
+        if self._tracker is None or not persist:
+            self._tracker = BYTETracker()
+        batch, originals = self._as_batch(source)
+        results = []
+        for i in range(int(batch.shape[0])):
+            res = self.predict(batch[i:i + 1], conf=conf, **kwargs)[0]
+            if originals is not None:
+                res.orig_img = originals[i]
+            det = res.boxes.data.numpy()
+            if len(det):
+                tracks = self._tracker.update(det)
+                if len(tracks):
+                    idx = tracks[:, -1].astype(int)
+                    res = res[idx]
+                    res.update(boxes=torch.as_tensor(tracks[:, :-1], dtype=torch.float32))
+            results.append(res)
+        return results
+
+    # ------------------------------------------------------------------------------------------ test hooks
+    def raw_head(self, source, imgsz: int = 640) -> np.ndarray:
+        """Pre-NMS head tensor ``[N, 4+nc+nk, A]`` exactly as ``Detect/Pose.forward`` returns it."""
+        lib = _lib.lib()
+        batch, _ = self._as_batch(source)
+        if isinstance(batch, torch.Tensor):
+            batch = batch.cpu().numpy()
+        n, h, w = batch.shape[:3]
+        ch, an = C.c_int(), C.c_int()
+        _lib.check(lib.mi355_yolo_raw_head(self._h, None, n, h, w, 0, imgsz, None, C.byref(ch), C.byref(an)))
+        out = np.empty((n, ch.value, an.value), dtype=np.float32)
+        with self._lock:
+            _lib.check(lib.mi355_yolo_raw_head(self._h, batch.ctypes.data, n, h, w, 0, imgsz, out.ctypes.data,
+                                               C.byref(ch), C.byref(an)))
+        return out
+
+    def set_profiling(self, on: bool = True) -> None:
+        _lib.check(_lib.lib().mi355_yolo_set_profiling(self._h, int(on)))
+
+    def last_timing(self) -> dict:
+        t = _lib.Timing()
+        _lib.check(_lib.lib().mi355_yolo_last_timing(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _lib.Timing._fields_}

@@ -1,0 +1,87 @@
+"""numpy wrappers over the single-operator C-ABI entry points (``mi355_op_*``).
+
+They exist so the parity tests can isolate one HIP kernel at a time; each call goes to the GPU
+(there is no CPU implementation behind them).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def conv2d(x_nhwc: np.ndarray, w_oihw: np.ndarray, bias: np.ndarray, stride: int = 1, silu: bool = True,
+           residual: Optional[np.ndarray] = None, device: int = 0) -> np.ndarray:
+    """Fused conv + bias (+SiLU) (+residual): x [N,H,W,Cin] fp32 -> [N,H/s,W/s,Cout]."""
+    x, w, b = _f32(x_nhwc), _f32(w_oihw), _f32(bias)
+    n, h, wd, cin = x.shape
+    cout, cin2, k, k2 = w.shape
+    if cin2 != cin or k != k2 or b.shape != (cout,):
+        raise ValueError("shape mismatch between x, w and bias")
+    y = np.empty((n, h // stride, wd // stride, cout), dtype=np.float32)
+    r = None
+    if residual is not None:
+        r = _f32(residual)
+        if r.shape != y.shape:
+            raise ValueError("residual must have the output's shape")
+    _lib.check(_lib.lib().mi355_op_conv2d(device, x.ctypes.data, n, h, wd, cin, w.ctypes.data, b.ctypes.data, cout, k,
+                                          stride, int(silu), r.ctypes.data if r is not None else None, y.ctypes.data))
+    return y
+
+
+def stem(bgr_u8: np.ndarray, w_oihw: np.ndarray, bias: np.ndarray, stride: int = 2, device: int = 0) -> np.ndarray:
+    """uint8 BGR frames [N,H,W,3] -> /255, RGB -> conv kxk + bias + SiLU -> [N,H/s,W/s,Cout]."""
+    img = np.ascontiguousarray(bgr_u8, dtype=np.uint8)
+    w, b = _f32(w_oihw), _f32(bias)
+    n, h, wd, _ = img.shape
+    cout, _, k, _ = w.shape
+    y = np.empty((n, h // stride, wd // stride, cout), dtype=np.float32)
+    _lib.check(_lib.lib().mi355_op_stem(device, img.ctypes.data, n, h, wd, w.ctypes.data, b.ctypes.data, cout, k,
+                                        stride, y.ctypes.data))
+    return y
+
+
+def letterbox_shape(h: int, w: int, imgsz: int = 640):
+    oh, ow = C.c_int(), C.c_int()
+    _lib.check(_lib.lib().mi355_letterbox_shape(h, w, imgsz, C.byref(oh), C.byref(ow)))
+    return oh.value, ow.value
+
+
+def letterbox(bgr_u8: np.ndarray, imgsz: int = 640, device: int = 0) -> np.ndarray:
+    img = np.ascontiguousarray(bgr_u8, dtype=np.uint8)
+    if img.ndim == 3:
+        img = img[None]
+    n, h, w, _ = img.shape
+    oh, ow = letterbox_shape(h, w, imgsz)
+    out = np.empty((n, oh, ow, 3), dtype=np.uint8)
+    _lib.check(_lib.lib().mi355_op_letterbox(device, img.ctypes.data, n, h, w, imgsz, out.ctypes.data))
+    return out
+
+
+def nms(pred: np.ndarray, nc: int, conf: float = 0.25, iou: float = 0.7, classes: Optional[Sequence[int]] = None,
+        max_det: int = 300, device: int = 0):
+    """non_max_suppression on pred [N, 4+nc+extra, A] -> list of (rows [n,6+extra], anchor_idx [n])."""
+    p = _f32(pred)
+    n, no, a = p.shape
+    extra = no - 4 - nc
+    rows = np.zeros((n, max_det, _lib.DET_WORDS), dtype=np.float32)
+    counts = np.zeros(n, dtype=np.int32)
+    cls_arr, ncls = None, 0
+    if classes is not None:
+        cls_arr = (C.c_int * len(classes))(*[int(c) for c in classes])
+        ncls = len(classes)
+    _lib.check(_lib.lib().mi355_op_nms(device, p.ctypes.data, n, nc, extra, a, conf, iou, cls_arr, ncls, max_det,
+                                       rows.ctypes.data, max_det, counts.ctypes.data_as(C.POINTER(C.c_int))))
+    out = []
+    for i in range(n):
+        r = rows[i, :counts[i]]
+        ints = r[:, 5:7].view(np.int32)
+        out.append((np.concatenate([r[:, :5], ints[:, :1].astype(np.float32), r[:, 7:7 + extra]], 1), ints[:, 1].copy()))
+    return out

@@ -1,0 +1,152 @@
+/*
+ * mi355_yolo.h -- C ABI of the MI355X-native YOLO detect/pose engine (libmi355yolo.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of
+ * cthadeufaria/computer-vision-shoplifting-detection: the per-frame Ultralytics call made at
+ *   /root/reference/model.py:18   self.model = YOLO("./models/yolov5mu.pt")
+ *   /root/reference/model.py:38   self.model.track(frame, persist=True, show=False, classes=[0], verbose=False)
+ *   /root/reference/model.py:40   results[0].boxes
+ * (driven per decoded frame by /root/reference/preprocess.py:38-47).  The arithmetic behind those
+ * calls lives in the un-vendored ultralytics==8.3.225 (requirements.txt:121); each entry point below
+ * names the Ultralytics function it replaces.  Plain pointers and sizes only: no torch / numpy /
+ * C++ types cross this boundary.  The Python facade (cvsd_amd.YOLO) binds it with ctypes; see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 (MI355_OK) or a negative MI355_E* code; mi355_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ *   - the caller owns every input/output buffer; the engine owns device memory, its HIP stream and
+ *     its weight copies.  One handle = one device = one in-order stream; infer calls on one handle
+ *     are NOT re-entrant (the reference is single-threaded; Ultralytics serialises predict with a lock).
+ *   - zero detections is not an error: the image's count is 0.
+ */
+#ifndef MI355_YOLO_H
+#define MI355_YOLO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_OK            0
+#define MI355_EINVAL       -1   /* bad argument (null pointer, non-positive size, capacity too small ...) */
+#define MI355_EIO          -2   /* weights file missing / unreadable */
+#define MI355_EFORMAT      -3   /* not a .mi355w file, or unsupported version / program */
+#define MI355_EHIP         -4   /* a HIP runtime call failed (message has the hipError string) */
+#define MI355_ENOMEM       -5
+
+#define MI355_TASK_DETECT   0
+#define MI355_TASK_POSE     1
+#define MI355_MAX_KPT_FLOATS 51   /* 17 keypoints x (x, y, conf) */
+
+typedef struct mi355_yolo mi355_yolo;   /* opaque engine handle */
+
+/* Engine options; zero-initialise and set struct_size = sizeof(mi355_opts). 0 means "default". */
+typedef struct mi355_opts {
+    int struct_size;
+    int batch_chunk;      /* frames pushed through the net per pass (default 16); larger batches are looped */
+    int reserved[6];
+} mi355_opts;
+
+/* One post-NMS detection, coordinates in ORIGINAL-image pixels (after scale_boxes / scale_coords).
+ * Replaces one row of Results.boxes.data (+ Results.keypoints.data) -- ultralytics/engine/results.py. */
+typedef struct mi355_det {
+    float x1, y1, x2, y2;
+    float conf;
+    int   cls;
+    int   anchor_idx;                      /* index of the source anchor in [0, A): P3 row-major, then P4, then P5 */
+    float kpt[MI355_MAX_KPT_FLOATS];       /* pose only: x, y, conf per keypoint; zeros for detect models */
+} mi355_det;
+
+typedef struct mi355_model_info {
+    int task;             /* MI355_TASK_* */
+    int nc;               /* number of classes */
+    int nkpt, kdim;       /* keypoint shape (17, 3) for pose, (0, 0) for detect */
+    int reg_max;          /* 16 */
+    int n_levels;
+    int strides[4];       /* 8, 16, 32 */
+    int n_convs, n_ops, n_buffers;
+    long long n_params;   /* fused parameter count incl. the 16 DFL weights (what Ultralytics' model.info() prints) */
+    long long macs_640;   /* multiply-accumulates of all convs for one 640x640 frame */
+    char family[8];       /* "v8" | "v5u" */
+    char scale;           /* 'n','s','m','l','x' */
+    char pad_[7];
+} mi355_model_info;
+
+/* Timing of the last infer call on this handle (HIP events on the engine's own stream). */
+typedef struct mi355_timing {
+    float total_ms;       /* preprocess .. NMS, device time, whole call */
+    float conv_ms;        /* sum over the implicit-GEMM conv launches (the dominant kernel) */
+    float stem_ms, pool_ms, upsample_ms, letterbox_ms, decode_ms, nms_ms;
+    int   conv_launches;
+    int   frames;
+} mi355_timing;
+
+const char* mi355_last_error(void);
+
+/* YOLO(path) -- ultralytics/engine/model.py:Model.__init__ + nn/tasks.py load + autobackend fuse.
+ * `weights_path` is a .mi355w file (fused weights + op program, written by cvsd_amd.weights). */
+int  mi355_yolo_create(const char* weights_path, int device_id, const mi355_opts* opts, mi355_yolo** out);
+/* Same, from an in-memory image of the file (what a rank receives from the RCCL weight broadcast). */
+int  mi355_yolo_create_from_memory(const void* blob, size_t nbytes, int device_id, const mi355_opts* opts,
+                                   mi355_yolo** out);
+void mi355_yolo_destroy(mi355_yolo* h);
+int  mi355_yolo_info(const mi355_yolo* h, mi355_model_info* info);
+
+/* model(frames, conf=, iou=, classes=, max_det=, imgsz=) -- engine/predictor.py:stream_inference:
+ * LetterBox + BGR->RGB + /255 (preprocess), the fused conv graph (nn/tasks.py:_predict_once), Detect/Pose
+ * decode (nn/modules/head.py), utils/nms.py:non_max_suppression, utils/ops.py:scale_boxes/scale_coords.
+ *   bgr_nhwc           n frames of h x w x 3 uint8, BGR (cv2 layout), HOST memory; consecutive rows are
+ *                      row_stride_bytes apart (0 = w*3) and consecutive frames h*row_stride_bytes apart
+ *   conf, iou          thresholds (Ultralytics predict defaults 0.25 / 0.7; .track() uses conf 0.1)
+ *   classes,n_classes  keep only detections whose best class is listed (NULL / 0 = all)   [classes=[0] at model.py:38]
+ *   max_det            at most this many rows per image (default 300)
+ *   imgsz              letterbox target (default 640; rectangular "auto" padding to a multiple of 32)
+ *   out_rows           [n * out_capacity_per_image] rows, image i at out_rows + i*out_capacity_per_image,
+ *                      confidence-descending (the NMS keep order)
+ *   out_counts         [n] rows written per image
+ */
+int  mi355_yolo_infer(mi355_yolo* h, const uint8_t* bgr_nhwc, int n, int height, int width, int row_stride_bytes,
+                      float conf, float iou, const int* classes, int n_classes, int max_det, int imgsz,
+                      mi355_det* out_rows, int out_capacity_per_image, int* out_counts);
+/* Same with the frames already resident in DEVICE memory (dense n x h x w x 3); outputs still go to host. */
+int  mi355_yolo_infer_device(mi355_yolo* h, const uint8_t* bgr_nhwc_dev, int n, int height, int width,
+                             float conf, float iou, const int* classes, int n_classes, int max_det, int imgsz,
+                             mi355_det* out_rows, int out_capacity_per_image, int* out_counts);
+
+/* The decoded pre-NMS head tensor, exactly the layout Detect/Pose.forward returns: out[n][4+nc+nk][A] fp32
+ * (xywh in letterboxed pixels, sigmoid class scores, decoded keypoints).  For parity tests.
+ * out may be NULL to query *out_channels / *out_anchors for the given frame size. */
+int  mi355_yolo_raw_head(mi355_yolo* h, const uint8_t* bgr_nhwc, int n, int height, int width, int row_stride_bytes,
+                         int imgsz, float* out, int* out_channels, int* out_anchors);
+
+/* Per-kernel-kind timing costs two HIP events per launch; off by default (total_ms is always measured). */
+int  mi355_yolo_set_profiling(mi355_yolo* h, int on);
+int  mi355_yolo_last_timing(const mi355_yolo* h, mi355_timing* t);
+
+/* ---- single-operator entry points (host pointers; used by the parity tests to isolate a kernel) -------- */
+
+/* Fused conv + bias (+SiLU) (+residual), NHWC fp32 -- ultralytics/nn/modules/conv.py:Conv.forward_fuse.
+ * x[n][h][w][cin] dense, w_oihw[cout][cin][k][k], bias[cout], residual (or NULL) and y dense [n][ho][wo][cout];
+ * k in {1,3}, stride in {1,2}, pad = k/2. */
+int  mi355_op_conv2d(int device_id, const float* x, int n, int h, int w, int cin, const float* w_oihw,
+                     const float* bias, int cout, int k, int stride, int silu, const float* residual, float* y);
+/* The u8 stem: letterboxed BGR frames -> (x/255, RGB) -> conv k x k stride s (pad k/2, or 2 for k=6) + bias + SiLU. */
+int  mi355_op_stem(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias,
+                   int cout, int k, int stride, float* y);
+/* data/augment.py:LetterBox on uint8 BGR frames (cv2.resize INTER_LINEAR fixed-point + 114 border).
+ * out must hold n * out_h * out_w * 3 bytes where (out_h,out_w) = mi355_letterbox_shape(). */
+int  mi355_letterbox_shape(int height, int width, int imgsz, int* out_h, int* out_w);
+int  mi355_op_letterbox(int device_id, const uint8_t* bgr, int n, int height, int width, int imgsz, uint8_t* out);
+/* utils/nms.py:non_max_suppression on a decoded head tensor pred[n][4+nc+extra][A] (Ultralytics layout).
+ * Rows come back in letterboxed pixels (no scale-back): x1,y1,x2,y2,conf,cls,anchor_idx, kpt = the `extra` columns. */
+int  mi355_op_nms(int device_id, const float* pred, int n, int nc, int extra, int anchors, float conf, float iou,
+                  const int* classes, int n_classes, int max_det, mi355_det* out_rows, int out_capacity_per_image,
+                  int* out_counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_YOLO_H */

@@ -1,0 +1,128 @@
+"""GPU parity of the whole hot path (frames -> rows) against the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# fp32 on both sides, different summation order through ~25 conv layers + DFL (x stride 32):
+RAW_BOX_TOL = 1e-2       # pre-NMS tensor, max over ALL 8400 anchors (fp32 conditioning)
+RAW_SCORE_TOL = 1e-4
+COORD_TOL = 1e-3         # north_star: post-NMS bbox / keypoint coordinates within 1e-3
+
+
+def _model(name, ckpt):
+    from cvsd_amd import YOLO
+    prog, sd = ckpt
+    return YOLO.from_state_dict(name, sd)
+
+
+@pytest.mark.parametrize("name", ["yolov8n", "yolov8n-pose"])
+def test_raw_head_small(name):
+    from oracle import yolo_oracle as O
+    from tools import synth
+    ckpt = synth.synthetic_checkpoint(name, seed=0)
+    m = _model(name, ckpt)
+    frames = synth.synthetic_frames(3, 64, 96, seed=11)
+    got = m.raw_head(frames, imgsz=96)
+    om = O.OracleModel(name, ckpt[1])
+    want = om.forward(O.preprocess(list(frames), 96)).numpy()
+    assert got.shape == want.shape
+    nc = om.nc
+    assert np.abs(got[:, :4] - want[:, :4]).max() < RAW_BOX_TOL
+    assert np.abs(got[:, 4:4 + nc] - want[:, 4:4 + nc]).max() < RAW_SCORE_TOL
+    if om.pose:
+        assert np.abs(got[:, 4 + nc:] - want[:, 4 + nc:]).max() < RAW_BOX_TOL
+
+
+def _compare_predictions(m, om, frames, conf, classes=None, max_det=300, imgsz=640):
+    from oracle import yolo_oracle as O
+    res = m.predict(frames, conf=conf, classes=classes, max_det=max_det, imgsz=imgsz)
+    want, _ = O.predict(om, list(frames), conf=conf, classes=classes, max_det=max_det, imgsz=imgsz)
+    stats = {"frames": len(frames), "rows": 0, "max_box_err": 0.0, "max_kpt_err": 0.0, "index_mismatch_frames": 0}
+    for r, w in zip(res, want):
+        ga, wa = r.anchor_idx, w["anchor_idx"].numpy()
+        if len(ga) != len(wa) or not np.array_equal(ga, wa):
+            stats["index_mismatch_frames"] += 1
+            continue
+        stats["rows"] += len(ga)
+        if len(ga) == 0:
+            continue
+        gb, wb = r.boxes.data.numpy(), w["boxes"].numpy()
+        assert np.array_equal(gb[:, 5], wb[:, 5])                      # identical class indices
+        stats["max_box_err"] = max(stats["max_box_err"], float(np.abs(gb[:, :4] - wb[:, :4]).max()))
+        assert np.abs(gb[:, 4] - wb[:, 4]).max() < RAW_SCORE_TOL
+        if om.pose:
+            stats["max_kpt_err"] = max(stats["max_kpt_err"],
+                                       float(np.abs(r.keypoints.data.numpy() - w["kpts"].numpy()).max()))
+    return stats
+
+
+@pytest.mark.parametrize("name,n", [("yolov8n", 2), ("yolov8n-pose", 4)])
+def test_predict_640_matches_oracle(name, n):
+    from oracle import yolo_oracle as O
+    from tools import synth
+    ckpt = synth.synthetic_checkpoint(name, seed=0)
+    m = _model(name, ckpt)
+    om = O.OracleModel(name, ckpt[1])
+    frames = synth.synthetic_frames(n, 640, 640, seed=5)
+    st = _compare_predictions(m, om, frames, conf=0.25)
+    print(name, st)
+    assert st["index_mismatch_frames"] == 0, st
+    assert st["rows"] > 0
+    assert st["max_box_err"] < COORD_TOL, st
+    assert st["max_kpt_err"] < COORD_TOL, st
+
+
+def test_predict_ucf_crime_shape_person_class(v8n):
+    """320x240 clips (UCF-Crime) -> rect letterbox 480x640 with a resize; classes=[0] as at model.py:38"""
+    from oracle import yolo_oracle as O
+    from tools import synth
+    m = _model("yolov8n", v8n)
+    om = O.OracleModel("yolov8n", v8n[1])
+    frames = synth.synthetic_frames(3, 240, 320, seed=2)
+    st = _compare_predictions(m, om, frames, conf=0.1, classes=None)
+    print(st)
+    assert st["index_mismatch_frames"] == 0, st
+    assert st["max_box_err"] < COORD_TOL, st
+    res = m.predict(frames, conf=0.1, classes=[0])
+    for r in res:
+        assert (r.boxes.cls == 0).all()
+
+
+def test_batch_larger_than_chunk_and_single_frame(v8n):
+    """batch looping inside the engine gives the same rows as frame-by-frame calls"""
+    from cvsd_amd import YOLO
+    from tools import synth
+    m = YOLO.from_state_dict("yolov8n", v8n[1], batch_chunk=4)
+    frames = synth.synthetic_frames(6, 128, 128, seed=9)
+    all_at_once = m.predict(frames, conf=0.1, imgsz=128)
+    for i, r in enumerate(all_at_once):
+        one = m.predict(frames[i], conf=0.1, imgsz=128)[0]
+        np.testing.assert_array_equal(r.boxes.data.numpy(), one.boxes.data.numpy())
+        np.testing.assert_array_equal(r.anchor_idx, one.anchor_idx)
+
+
+def test_device_resident_input(v8n):
+    m = _model("yolov8n", v8n)
+    from tools import synth
+    frames = synth.synthetic_frames(2, 128, 128, seed=4)
+    host = m.predict(frames, conf=0.1, imgsz=128)
+    dev = m.predict(torch.from_numpy(frames).cuda(), conf=0.1, imgsz=128)
+    for a, b in zip(host, dev):
+        np.testing.assert_array_equal(a.boxes.data.numpy(), b.boxes.data.numpy())
+
+
+def test_errors(v8n, tmp_path):
+    from cvsd_amd import YOLO
+    with pytest.raises(FileNotFoundError):
+        YOLO(str(tmp_path / "missing.mi355w"))
+    bad = tmp_path / "bad.mi355w"
+    bad.write_bytes(b"not a weight file")
+    with pytest.raises(ValueError):
+        YOLO(str(bad))
+    m = _model("yolov8n", v8n)
+    with pytest.raises(ValueError):
+        m.predict(np.zeros((4, 4), np.uint8))
+    empty = m.predict(np.zeros((64, 64, 3), np.uint8), conf=0.999999, imgsz=64)[0]
+    assert len(empty.boxes) == 0 and not empty.boxes.is_track

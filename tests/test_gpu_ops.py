@@ -1,0 +1,146 @@
+"""GPU parity of single HIP kernels against the oracle / plain torch fp32, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_conv(x, w, b, stride, silu, res):
+    y = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(w), torch.from_numpy(b), stride=stride,
+                 padding=w.shape[2] // 2)
+    if silu:
+        y = F.silu(y)
+    y = y.permute(0, 2, 3, 1).contiguous().numpy()
+    return y + res if res is not None else y
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, silu, residual
+    (2, 20, 20, 16, 16, 3, 1, True, True),
+    (1, 40, 40, 32, 64, 3, 2, True, False),
+    (2, 16, 24, 64, 80, 3, 1, True, False),
+    (1, 80, 80, 64, 64, 3, 1, True, True),
+    (2, 20, 20, 256, 128, 1, 1, True, False),
+    (1, 40, 40, 384, 128, 1, 1, True, False),
+    (3, 20, 20, 51, 51, 3, 1, True, False),       # pose kpt branch: channel counts not multiples of 4
+    (2, 20, 20, 51, 51, 1, 1, False, False),
+    (2, 40, 40, 64, 1, 1, 1, False, False),       # pose cls output (nc = 1)
+    (1, 20, 20, 80, 80, 1, 1, False, False),
+    (1, 32, 32, 48, 96, 3, 2, True, False),       # v8m widths
+    (1, 20, 20, 128, 256, 3, 2, True, False),
+    (1, 8, 8, 576, 576, 3, 1, True, True),
+    (5, 12, 20, 32, 32, 3, 1, True, False),       # ragged: tile does not divide the map
+    (1, 160, 160, 16, 32, 3, 2, True, False),
+]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,stride,silu,residual", CONV_CASES)
+def test_conv2d_matches_torch(n, h, w, cin, cout, k, stride, silu, residual):
+    from cvsd_amd import ops
+    rng = np.random.default_rng(cin * 1000 + cout + k)
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wt = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((n, h // stride, w // stride, cout), dtype=np.float32) if residual else None
+    y = ops.conv2d(x, wt, b, stride=stride, silu=silu, residual=res)
+    ref = _ref_conv(x, wt, b, stride, silu, res)
+    assert y.shape == ref.shape
+    # fp32 with a different summation order: tolerance 2e-5 absolute on O(1) outputs
+    np.testing.assert_allclose(y, ref, rtol=2e-5, atol=2e-5)
+
+
+def test_conv2d_asymmetric_identity():
+    """A = I check with an asymmetric operand (catches a transposed MFMA fragment map)."""
+    from cvsd_amd import ops
+    cin = cout = 32
+    x = np.arange(2 * 4 * 4 * cin, dtype=np.float32).reshape(2, 4, 4, cin) % 97
+    w = np.zeros((cout, cin, 1, 1), np.float32)
+    for o in range(cout):
+        w[o, (o * 7 + 3) % cin, 0, 0] = 1.0          # a permutation, not symmetric
+    y = ops.conv2d(x, w, np.zeros(cout, np.float32), silu=False)
+    ref = x[..., [(o * 7 + 3) % cin for o in range(cout)]]
+    np.testing.assert_array_equal(y, ref)
+
+
+@pytest.mark.parametrize("k,cout,h,w", [(3, 16, 64, 96), (3, 48, 32, 32), (6, 16, 64, 64), (3, 32, 640, 640)])
+def test_stem_matches_torch(k, cout, h, w):
+    from cvsd_amd import ops
+    rng = np.random.default_rng(k + cout)
+    img = rng.integers(0, 256, size=(2, h, w, 3), dtype=np.uint8)
+    wt = (rng.standard_normal((cout, 3, k, k)) / np.sqrt(3 * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    y = ops.stem(img, wt, b, stride=2)
+    x = torch.from_numpy(np.ascontiguousarray(img[..., ::-1].transpose(0, 3, 1, 2))).float()
+    x /= 255
+    ref = F.silu(F.conv2d(x, torch.from_numpy(wt), torch.from_numpy(b), stride=2, padding=2 if k == 6 else 1))
+    np.testing.assert_allclose(y, ref.permute(0, 2, 3, 1).numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("h,w", [(240, 320), (720, 1280), (480, 640), (100, 37), (640, 640), (1080, 1920)])
+def test_letterbox_bit_exact(h, w):
+    """integer work: bit-exact against the oracle's cv2.resize/LetterBox restatement"""
+    from cvsd_amd import ops
+    from oracle import yolo_oracle as O
+    rng = np.random.default_rng(h + w)
+    img = rng.integers(0, 256, size=(2, h, w, 3), dtype=np.uint8)
+    out = ops.letterbox(img, 640)
+    ref = np.stack([O.letterbox(f, (640, 640)) for f in img])
+    assert out.shape == ref.shape
+    np.testing.assert_array_equal(out, ref)
+
+
+def _random_pred(rng, n, nc, extra, a, frac=0.05):
+    pred = np.zeros((n, 4 + nc + extra, a), np.float32)
+    pred[:, 0] = rng.uniform(0, 640, (n, a))
+    pred[:, 1] = rng.uniform(0, 640, (n, a))
+    pred[:, 2] = rng.uniform(8, 300, (n, a))
+    pred[:, 3] = rng.uniform(8, 300, (n, a))
+    sc = rng.uniform(0, 0.2, (n, nc, a)).astype(np.float32)
+    hot = rng.random((n, a)) < frac
+    cls = rng.integers(0, nc, (n, a))
+    for i in range(n):
+        idx = np.nonzero(hot[i])[0]
+        sc[i, cls[i, idx], idx] = rng.uniform(0.2, 1.0, len(idx))
+    pred[:, 4:4 + nc] = sc
+    if extra:
+        pred[:, 4 + nc:] = rng.standard_normal((n, extra, a))
+    return pred
+
+
+@pytest.mark.parametrize("nc,extra,a,frac,classes,max_det", [
+    (80, 0, 8400, 0.05, None, 300),
+    (1, 51, 8400, 0.10, None, 300),
+    (80, 0, 8400, 0.30, [0, 3, 17], 300),
+    (3, 0, 2100, 1.00, None, 300),        # every anchor is a candidate; max_det truncation
+    (80, 0, 8400, 0.0, None, 300),        # no candidates at all
+    (2, 4, 525, 0.5, [1], 50),
+])
+def test_nms_matches_oracle(nc, extra, a, frac, classes, max_det):
+    from cvsd_amd import ops
+    from oracle import yolo_oracle as O
+    rng = np.random.default_rng(nc + extra + a)
+    pred = _random_pred(rng, 3, nc, extra, a, frac)
+    got = ops.nms(pred, nc, conf=0.25, iou=0.7, classes=classes, max_det=max_det)
+    want, idxs = O.non_max_suppression(torch.from_numpy(pred), 0.25, 0.7, classes=classes, max_det=max_det, nc=nc,
+                                       return_idxs=True)
+    for (rows, anchors), wr, wi in zip(got, want, idxs):
+        assert len(rows) == len(wr)
+        np.testing.assert_array_equal(anchors, wi.numpy())           # identical box indices, identical order
+        np.testing.assert_array_equal(rows, wr.numpy())              # same fp32 op order -> bit-exact rows
+
+
+def test_nms_score_ties_are_stable():
+    """equal scores keep ascending anchor order (torch's stable sort)"""
+    from cvsd_amd import ops
+    from oracle import yolo_oracle as O
+    a = 512
+    pred = np.zeros((1, 5, a), np.float32)
+    pred[0, 0] = (np.arange(a) % 32) * 20 + 10
+    pred[0, 1] = (np.arange(a) // 32) * 40 + 10
+    pred[0, 2:4] = 30
+    pred[0, 4] = 0.5
+    (rows, anchors), = ops.nms(pred, 1)
+    want, idx = O.non_max_suppression(torch.from_numpy(pred), nc=1, return_idxs=True)
+    np.testing.assert_array_equal(anchors, idx[0].numpy())
