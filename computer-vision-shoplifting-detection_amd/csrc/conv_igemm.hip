@@ -15,13 +15,16 @@
 // Block = 256 threads = 4 waves, arranged WP (along pixels) x WC (along couts); a wave owns PT pixel tiles
 // x CT cout tiles of 16x16.  The input tile (with halo) is staged through LDS in chunks of `ck` channels.
 #include "common.h"
+#include "detmath.h"
+
+#pragma clang fp contract(off)
 
 namespace mi355 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float silu_f(float v) { return det_silu(v); }
 
 template <int KS, int STRIDE, int PT, int CT, int WP>
 __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
@@ -75,10 +78,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
         const int rem = a.Cin - c0;
         const int nkk = ((rem < a.ck ? rem : a.ck) + 15) >> 4;
         const int cib0 = c0 >> 4;
+        // canonical accumulation order of one output: 16-channel block (outer), tap, MFMA step s, k-group g
+        for (int kk = 0; kk < nkk; ++kk) {
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int tapoff = ((tap / KS) * a.TWin + (tap % KS)) * a.ldp;
-            for (int kk = 0; kk < nkk; ++kk) {
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int tapoff = ((tap / KS) * a.TWin + (tap % KS)) * a.ldp;
                 f32x4 wf[CT], xf[PT];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {

@@ -1,0 +1,33 @@
+// Canonical fp32 transcendental of the engine (DESIGN.md "canonical arithmetic"): a libm-free exp built from
+// fmaf / mul / add only, so that a CPU restatement (oracle/det_oracle.c states the same sequence) reproduces
+// every SiLU, sigmoid and DFL softmax of the GPU path bit for bit.  <= 1.4 ulp from the true exp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mi355 {
+
+__device__ __forceinline__ float det_expf(float x) {
+    x = __builtin_fminf(__builtin_fmaxf(x, -104.0f), 89.0f);
+    const float t = __builtin_fmaf(x, 1.44269504088896341f, 12582912.0f);   // round(x * log2 e), ties to even
+    const float n = t - 12582912.0f;
+    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    r = __builtin_fmaf(n, -1.428606765330187045e-06f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    float e = __builtin_fmaf(p, r2, r);
+    e = e + 1.0f;
+    const int ni = (int)n;
+    const int n1 = ni / 2, n2 = ni - n1;
+    const float s1 = __int_as_float((n1 + 127) << 23), s2 = __int_as_float((n2 + 127) << 23);
+    return (e * s1) * s2;
+}
+
+__device__ __forceinline__ float det_silu(float v) { return v / (1.0f + det_expf(-v)); }
+__device__ __forceinline__ float det_sigmoid(float v) { return 1.0f / (1.0f + det_expf(-v)); }
+
+}  // namespace mi355

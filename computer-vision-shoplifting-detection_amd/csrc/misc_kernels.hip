@@ -1,12 +1,15 @@
 // Bandwidth-bound kernels around the conv stack: the u8 stem conv, nearest 2x upsample, the SPPF max-pools
 // and the letterbox resize/pad.  All NHWC, 16-byte accesses per lane wherever the layout allows.
 #include "common.h"
+#include "detmath.h"
+
+#pragma clang fp contract(off)
 
 namespace mi355 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float silu_m(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float silu_m(float v) { return det_silu(v); }
 
 // ---------------------------------------------------------------------------------------------- stem
 // model.0: Conv(3 -> Cout, k, s) on the letterboxed uint8 BGR frame.  Fuses the rest of
@@ -53,7 +56,8 @@ __global__ __launch_bounds__(256) void stem_conv_u8(StemArgs a) {
             for (int cb = 0; cb < 3; ++cb) {
                 const float v = lut[px[cb]];
                 const f32x4 w4 = *(const f32x4*)(wr + cb * cout4);
-                acc += v * w4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(v, w4[j], acc[j]);   // canonical chain: kh, kw, (B,G,R)
             }
         }
     }

@@ -8,6 +8,7 @@
 // reached from /root/reference/model.py:38-40.
 #include "common.h"
 #include "../../include/mi355_yolo.h"
+#include "detmath.h"
 
 #pragma clang fp contract(off)
 
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
         for (int j = 1; j < 16; ++j) m = fmaxf(m, v[j]);
         float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { v[j] = expf(v[j] - m); sum += v[j]; }
+        for (int j = 0; j < 16; ++j) { v[j] = det_expf(v[j] - m); sum += v[j]; }
         float d = 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) d += (v[j] / sum) * (float)j;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     out[3] = (y2 - y1) * st;
     float best = -1.f; int bi = 0;
     for (int c = 0; c < a.nc; ++c) {
-        const float s = 1.0f / (1.0f + expf(-p[lv.cls_off + c]));
+        const float s = det_sigmoid(p[lv.cls_off + c]);
         out[4 + c] = s;
         if (s > best) { best = s; bi = c; }
     }
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
         float* ko = out + 4 + a.nc + k * a.kdim;
         ko[0] = (kp[0] * 2.0f + (ax - 0.5f)) * st;
         ko[1] = (kp[1] * 2.0f + (ay - 0.5f)) * st;
-        if (a.kdim == 3) ko[2] = 1.0f / (1.0f + expf(-kp[2]));
+        if (a.kdim == 3) ko[2] = det_sigmoid(kp[2]);
     }
 }
 

@@ -51,6 +51,22 @@ def test_conv2d_matches_torch(n, h, w, cin, cout, k, stride, silu, residual):
     np.testing.assert_allclose(y, ref, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,k,stride,silu,residual", CONV_CASES)
+def test_conv2d_bit_exact_vs_canonical_order_oracle(n, h, w, cin, cout, k, stride, silu, residual):
+    """The fp32 MFMA is a k-ordered fma chain: against the C oracle that states the same order (and the same
+    libm-free exp) the conv output must be identical bit for bit."""
+    from cvsd_amd import ops
+    from oracle import det
+    rng = np.random.default_rng(cin * 1000 + cout + k + 1)
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wt = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((n, h // stride, w // stride, cout), dtype=np.float32) if residual else None
+    y = ops.conv2d(x, wt, b, stride=stride, silu=silu, residual=res)
+    ref = det.conv2d(x, wt, b, stride=stride, act=silu, residual=res)
+    np.testing.assert_array_equal(y, ref)
+
+
 def test_conv2d_asymmetric_identity():
     """A = I check with an asymmetric operand (catches a transposed MFMA fragment map)."""
     from cvsd_amd import ops
@@ -76,6 +92,17 @@ def test_stem_matches_torch(k, cout, h, w):
     x /= 255
     ref = F.silu(F.conv2d(x, torch.from_numpy(wt), torch.from_numpy(b), stride=2, padding=2 if k == 6 else 1))
     np.testing.assert_allclose(y, ref.permute(0, 2, 3, 1).numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("k,cout,h,w", [(3, 16, 64, 96), (3, 48, 32, 32), (6, 16, 64, 64), (3, 32, 640, 640)])
+def test_stem_bit_exact_vs_canonical_order_oracle(k, cout, h, w):
+    from cvsd_amd import ops
+    from oracle import det
+    rng = np.random.default_rng(k + cout + 7)
+    img = rng.integers(0, 256, size=(2, h, w, 3), dtype=np.uint8)
+    wt = (rng.standard_normal((cout, 3, k, k)) / np.sqrt(3 * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    np.testing.assert_array_equal(ops.stem(img, wt, b, stride=2), det.stem(img, wt, b, stride=2))
 
 
 @pytest.mark.parametrize("h,w", [(240, 320), (720, 1280), (480, 640), (100, 37), (640, 640), (1080, 1920)])

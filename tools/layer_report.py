@@ -1,0 +1,47 @@
+"""Per-layer roofline table from a rocprofv3 kernel trace of bench.py (test/bench infrastructure).
+
+    python tools/layer_report.py gpurun_out/prof/.../*_kernel_trace.csv [model] [chunk]
+
+Matches the dispatch sequence of one engine pass (stem, program ops..., decode, nms) against the op program and
+prints, per conv launch, the median duration over all passes, achieved TFLOP/s and the layer's algorithmic bytes."""
+import csv, sys, os, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cvsd_amd.graph import build_program, parse_model_name, OP_CONV, OP_STEM, OP_UPSAMPLE, OP_SPPF_POOL
+
+path = sys.argv[1]
+model = sys.argv[2] if len(sys.argv) > 2 else "yolov8n"
+chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+size = int(sys.argv[4]) if len(sys.argv) > 4 else 640
+prog = build_program(*parse_model_name(model))
+rows = [r for r in csv.DictReader(open(path)) if "mi355::" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+seq = []
+for op in prog.ops:
+    seq.append({OP_STEM: "stem_conv_u8", OP_CONV: "conv_igemm_f32", OP_UPSAMPLE: "upsample2x", OP_SPPF_POOL: "sppf_pools"}[op.type])
+seq += ["decode_kernel", "nms_sort_kernel", "nms_greedy_kernel"]
+# split the trace into passes
+passes, i = [], 0
+while i + len(seq) <= len(rows):
+    if all(seq[j] in rows[i + j]["Kernel_Name"] for j in range(len(seq))):
+        passes.append(rows[i:i + len(seq)]); i += len(seq)
+    else:
+        i += 1
+print(f"{len(passes)} passes of {len(seq)} launches matched ({model}, chunk {chunk})")
+tot = 0.0
+print(f"{'op':26s} {'kernel<KS,S,PT,CT,WP>':24s} {'shape':30s} {'grid':>12s} {'lds':>6s} {'vgpr':>5s} {'us':>8s} {'TFLOP/s':>8s} {'GB/s':>7s}")
+for j, name in enumerate(seq):
+    d = [(int(p[j]["End_Timestamp"]) - int(p[j]["Start_Timestamp"])) / 1e3 for p in passes]
+    us = statistics.median(d); tot += us
+    r = passes[0][j]
+    kn = r["Kernel_Name"]
+    tmpl = kn[kn.find("<"):kn.find(">") + 1] if "<" in kn else ""
+    if j < len(prog.ops) and prog.ops[j].type in (OP_CONV, OP_STEM):
+        op = prog.ops[j]; c = prog.convs[op.conv]
+        hw = (size // c.stride_div) ** 2
+        fl = 2.0 * c.cout * c.cin * c.k * c.k * hw * chunk
+        by = 4.0 * chunk * (c.cin * hw * c.s * c.s + c.cout * hw)
+        print(f"{c.name:26s} {tmpl:24s} {f'{c.cin}->{c.cout} k{c.k}s{c.s} @{size//c.stride_div}':30s} "
+              f"{r['Grid_Size_X'] + 'x' + r['Grid_Size_Y']:>12s} {r['LDS_Block_Size']:>6s} {int(r['VGPR_Count'])+int(r['Accum_VGPR_Count']):>5d} {us:8.1f} {fl / us / 1e6:8.2f} {by / us / 1e3:7.0f}")
+    else:
+        print(f"{name:26s} {'':24s} {'':30s} {r['Grid_Size_X'] + 'x' + r['Grid_Size_Y']:>12s} {r['LDS_Block_Size']:>6s} {int(r['VGPR_Count'])+int(r['Accum_VGPR_Count']):>5d} {us:8.1f}")
+print(f"sum of medians: {tot:.1f} us per pass of {chunk} frames -> {chunk / tot * 1e6:.0f} frames/s device-only")
