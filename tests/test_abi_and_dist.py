@@ -1,0 +1,98 @@
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """the C-ABI library loads (no GPU needed for that) and exports each function include/mi355_yolo.h declares"""
+    import ctypes
+    from cvsd_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mi355_yolo.h")).read()
+    declared = set(re.findall(r"\b(mi355_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    handle = _lib.lib()
+    for name in declared:
+        assert getattr(handle, name) is not None
+    assert ctypes.sizeof(_lib.Det) == 4 * 58
+
+
+def test_no_gpu_is_a_loud_error_not_a_fallback(v8n):
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from cvsd_amd import YOLO, ops
+    from cvsd_amd._lib import Mi355Error
+    with pytest.raises((Mi355Error, ValueError)):
+        YOLO.from_state_dict("yolov8n", v8n[1])
+    with pytest.raises((Mi355Error, ValueError)):
+        ops.conv2d(np.zeros((1, 4, 4, 16), np.float32), np.zeros((16, 16, 1, 1), np.float32), np.zeros(16, np.float32))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "computer-vision-shoplifting-detection_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+(oracle|tools)\b", src, re.M), f
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    from cvsd_amd import dist as cd
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        blob = bytes(range(256)) * 37 if rank == 0 else None
+        got = cd.broadcast_weights(blob)                                   # C1
+        assert got == bytes(range(256)) * 37
+        lo, hi = cd.shard_range(10, rank, world)
+        rows = np.zeros((hi - lo, 4, 58), np.float32)
+        counts = np.array([(lo + i) % 4 for i in range(hi - lo)], np.int32)
+        for i in range(hi - lo):
+            rows[i, :counts[i], 0] = 100 * (lo + i) + np.arange(counts[i])
+        blocks, all_counts = cd.gather_rows(rows, counts)                  # C2 + C3
+        if rank == 0:
+            flat = np.concatenate(blocks)[:, 0]
+            want = np.concatenate([100 * f + np.arange(f % 4) for f in range(10)])
+            assert np.array_equal(flat, want) and np.concatenate(all_counts).tolist() == [f % 4 for f in range(10)]
+            out.put("ok")
+        else:
+            assert blocks is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_broadcast_and_gather():
+    """N>1 path on CPU: weight broadcast and ordered row gather with world_size 2 (gloo)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get(timeout=5) == "ok"
+
+
+def test_shard_range_covers_everything():
+    from cvsd_amd.dist import shard_range
+    for total in (0, 1, 7, 64, 145):
+        for world in (1, 2, 4, 8):
+            r = [shard_range(total, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == total and all(a[1] == b[0] for a, b in zip(r, r[1:]))

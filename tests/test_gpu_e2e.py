@@ -175,3 +175,37 @@ def test_errors(v8n, tmp_path):
         m.predict(np.zeros((4, 4), np.uint8))
     empty = m.predict(np.zeros((64, 64, 3), np.uint8), conf=1.0, imgsz=64)[0]      # scores are <= 1 and the test is strict
     assert len(empty.boxes) == 0 and not empty.boxes.is_track
+
+
+@pytest.mark.parametrize("name", ["yolov8n", "yolov8n-pose"])
+def test_engine_matches_committed_golden_vectors(name):
+    """tests/golden/golden_v1.npz (written in the build container by tools/make_golden.py from the canonical-order
+    oracle): head tensor of 2 small frames and the post-NMS rows of 2 frames at 640x640 -- bit for bit."""
+    import os
+    from tools import synth
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v1.npz"))
+    ckpt = synth.synthetic_checkpoint(name, seed=0)
+    m = _model(name, ckpt)
+    np.testing.assert_array_equal(m.raw_head(synth.synthetic_frames(2, 64, 96, seed=11), imgsz=96), g[f"head_64x96/{name}"])
+    res = m.predict(synth.synthetic_frames(2, 640, 640, seed=21), conf=0.25)
+    for i, r in enumerate(res):
+        np.testing.assert_array_equal(r.anchor_idx, g[f"rows_640/{name}/{i}/anchors"])
+        np.testing.assert_array_equal(r.boxes.data.numpy(), g[f"rows_640/{name}/{i}/boxes"])
+        if name.endswith("pose"):
+            k = g[f"rows_640/{name}/{i}/kpts"].copy()
+            k[..., :2][k[..., 2] < 0.5] = 0
+            np.testing.assert_array_equal(r.keypoints.data.numpy(), k)
+
+
+def test_track_call_of_the_reference(v8n):
+    """model.track(frame, persist=True, show=False, classes=[0], verbose=False) -> boxes with ids (model.py:38-45)"""
+    from tools import synth
+    m = _model("yolov8n", v8n)
+    frames = synth.synthetic_frames(3, 240, 320, seed=8)
+    seen = 0
+    for f in frames:
+        boxes = m.track(f, persist=True, show=False, classes=None, verbose=False)[0].boxes
+        if boxes.is_track:
+            seen += 1
+            assert boxes.data.shape[1] == 7 and float(boxes[0].id) >= 1 and boxes.xywhn.shape[1] == 4
+    assert seen >= 1

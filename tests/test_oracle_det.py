@@ -1,0 +1,69 @@
+"""The canonical-order C oracle: pinned by the golden vectors and bounded against the torch oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import det
+from oracle import yolo_oracle as O
+from tools import synth
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v1.npz"))
+
+
+def test_det_expf_accuracy_and_golden():
+    x = np.linspace(-87, 88, 200001).astype(np.float32)
+    e = det.expf(x)
+    ref = np.exp(x.astype(np.float64))
+    assert np.max(np.abs(e - ref) / ref) < 1.2e-7                     # <= ~1.5 ulp
+    assert det.expf(np.array([0.0], np.float32))[0] == 1.0
+    assert det.expf(np.array([-200.0], np.float32))[0] == 0.0 and np.isinf(det.expf(np.array([100.0], np.float32))[0])
+    np.testing.assert_array_equal(det.expf(G["expf/x"]), G["expf/y"])
+
+
+@pytest.mark.parametrize("tag", ["conv3x3_s1_res", "conv3x3_s2", "conv1x1_51"])
+def test_conv_golden_and_vs_torch(tag):
+    x, w, b = G[f"{tag}/x"], G[f"{tag}/w"], G[f"{tag}/b"]
+    k, s, act = G[f"{tag}/meta"]
+    res = G[f"{tag}/res"] if f"{tag}/res" in G else None
+    y = det.conv2d(x, w, b, stride=int(s), act=bool(act), residual=res)
+    np.testing.assert_array_equal(y, G[f"{tag}/y"])                    # bit-exact on every host
+    ref = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(w), torch.from_numpy(b), stride=int(s), padding=int(k) // 2)
+    if act:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1).numpy()
+    if res is not None:
+        ref = ref + res
+    np.testing.assert_allclose(y, ref, rtol=2e-5, atol=2e-5)           # same function as torch's conv
+
+
+@pytest.mark.parametrize("name", ["yolov8n", "yolov8n-pose"])
+def test_full_net_golden_head(name):
+    prog, sd = synth.synthetic_checkpoint(name, seed=0)
+    dm = det.DetOracleModel(name, sd)
+    frames = synth.synthetic_frames(2, 64, 96, seed=11)
+    _, pred = det.predict(dm, list(frames), conf=0.25, imgsz=96)
+    np.testing.assert_array_equal(pred.numpy(), G[f"head_64x96/{name}"])
+    # and it is the same function as the torch oracle, up to fp32 re-association noise
+    want = O.OracleModel(name, sd).forward(O.preprocess(list(frames), 96)).numpy()
+    assert np.abs(pred.numpy() - want).max() < 2e-2 and np.abs(pred.numpy() - want).mean() < 1e-4
+
+
+def test_det_vs_torch_oracle_640_statistics():
+    """documents the noise floor any fp32 implementation has against torch's CPU kernels"""
+    name = "yolov8n"
+    prog, sd = synth.synthetic_checkpoint(name, seed=0)
+    frames = synth.synthetic_frames(1, 640, 640, seed=21)
+    rd, pd_ = det.predict(det.DetOracleModel(name, sd), list(frames))
+    ro, po = O.predict(O.OracleModel(name, sd), list(frames))
+    d = np.abs(pd_.numpy() - po.numpy())
+    assert d[:, :4].max() < 5e-2 and d[:, :4].mean() < 5e-4 and d[:, 4:].max() < 1e-3
+    np.testing.assert_array_equal(rd[0]["boxes"].numpy(), G[f"rows_640/{name}/0/boxes"])
+    np.testing.assert_array_equal(rd[0]["anchor_idx"].numpy(), G[f"rows_640/{name}/0/anchors"])
+
+
+@pytest.mark.parametrize("tag", ["lb_30x40", "lb_48x48", "lb_100x37"])
+def test_letterbox_golden(tag):
+    np.testing.assert_array_equal(O.letterbox(G[f"{tag}/in"], (64, 64)), G[f"{tag}/out"])

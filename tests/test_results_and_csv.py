@@ -1,0 +1,117 @@
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cvsd_amd.results import Boxes, Keypoints, Results
+from cvsd_amd.tracker_csv import ANOMALIES, BBox, Tracker, write_rows
+
+
+def test_boxes_surface_used_by_reference():
+    """model.py:45,56-67: is_track, iteration -> 1-row Boxes, float(box.id), box.xywhn[0][k]"""
+    data = torch.tensor([[100.0, 50.0, 300.0, 250.0, 7.0, 0.9, 0.0], [0.0, 0.0, 64.0, 48.0, 9.0, 0.5, 0.0]])
+    b = Boxes(data, (240, 320))
+    assert b.is_track and len(b) == 2
+    rows = [box for box in b]
+    assert len(rows) == 2 and all(isinstance(r, Boxes) and r.data.shape == (1, 7) for r in rows)
+    assert float(rows[0].id) == 7.0
+    np.testing.assert_allclose(rows[0].xywhn[0].numpy(), [200 / 320, 150 / 240, 200 / 320, 200 / 240], rtol=1e-7)
+    assert b.conf.tolist() == [0.8999999761581421, 0.5] and b.cls.tolist() == [0.0, 0.0]
+    nb = Boxes(data[:, [0, 1, 2, 3, 5, 6]], (240, 320))
+    assert not nb.is_track and nb.id is None
+    np.testing.assert_allclose(nb.xyxyn[1].numpy(), [0, 0, 0.2, 0.2], rtol=1e-7)
+    assert isinstance(nb.numpy().data, np.ndarray) and len(Boxes(torch.zeros(0, 6), (4, 4))) == 0
+
+
+def test_keypoints_low_conf_zeroed():
+    k = torch.tensor([[[10.0, 20.0, 0.9], [30.0, 40.0, 0.4]]])
+    kp = Keypoints(k, (100, 200))
+    assert kp.xy.tolist() == [[[10.0, 20.0], [0.0, 0.0]]] and kp.has_visible
+    np.testing.assert_allclose(kp.xyn[0, 0].numpy(), [0.05, 0.2])
+    assert kp.conf.tolist() == [[0.8999999761581421, 0.4000000059604645]]
+
+
+def test_results_index_and_update():
+    r = Results(None, "x.jpg", {0: "person"}, boxes=torch.rand(3, 6), keypoints=torch.rand(3, 17, 3), orig_shape=(48, 64))
+    sub = r[[2, 0]]
+    assert len(sub) == 2 and sub.keypoints.data.shape == (2, 17, 3)
+    sub.update(boxes=torch.rand(2, 7))
+    assert sub.boxes.is_track
+
+
+GOLDEN_CSV = (
+    "7,Shoplifting003_x264.mp4,12,3.0,0.625,0.625,0.625,0.8333333134651184,True,Shoplifting\r\n"
+    "7,Shoplifting003_x264.mp4,12,5.0,0.10000000149011612,0.10000000149011612,0.20000000298023224,0.20000000298023224,True,Shoplifting\r\n"
+)
+
+
+class _FakeModel:
+    def __init__(self, rows):
+        self.rows = rows
+
+    def track(self, frame, persist=True, show=False, classes=None, verbose=False):
+        assert persist and classes == [0] and not show and not verbose          # the reference's literal call
+        data = torch.tensor(self.rows, dtype=torch.float32).reshape(-1, 7 if self.rows and len(self.rows[0]) == 7 else 6)
+        return [Results(frame, "f", {0: "person"}, boxes=data, orig_shape=frame.shape[:2])]
+
+
+def test_csv_rows_byte_for_byte(tmp_path):
+    """dataclass-csv semantics: astuple -> csv.writer (excel dialect), no header, append; left/top = box centre"""
+    frame = np.zeros((240, 320, 3), np.uint8)
+    m = _FakeModel([[100.0, 50.0, 300.0, 250.0, 3.0, 0.9, 0.0], [0.0, 0.0, 64.0, 48.0, 5.0, 0.5, 0.0]])
+    t = Tracker(model=m, out_dir=str(tmp_path))
+    rows = t.save_to_dataset(frame, 7, 12.0, "Shoplifting", "Shoplifting003_x264.mp4")
+    assert isinstance(rows[0], BBox) and rows[0].frame == 12 and rows[0].is_anomaly
+    p = tmp_path / "ucf-crime_dataset.csv"
+    assert p.read_bytes().decode() == GOLDEN_CSV
+    t.save_to_dataset(frame, 7, 13.0, "Shoplifting", "Shoplifting003_x264.mp4")          # append, never truncate
+    assert p.read_bytes().decode().count("\r\n") == 4
+    t.save_to_dataset(frame, 8, 1.0, "Shopping", "Shopping001_x264.mp4")                  # normal label -> other file
+    assert (tmp_path / "ucf-crime_dataset-normal.csv").read_bytes().decode().startswith("8,Shopping001_x264.mp4,1,3.0,")
+    assert "Shopping" not in ANOMALIES and "Shoplifting" in ANOMALIES
+
+
+def test_untracked_frame_is_dropped(tmp_path):
+    t = Tracker(model=_FakeModel([[1.0, 2.0, 3.0, 4.0, 0.9, 0.0]]), out_dir=str(tmp_path))
+    assert t.save_to_dataset(np.zeros((8, 8, 3), np.uint8), 1, 1.0, "Shoplifting", "x") is None
+    assert not os.listdir(tmp_path)
+    with pytest.raises(TypeError):
+        write_rows(str(tmp_path / "x.csv"), [("not", "a", "BBox")])
+
+
+def test_preprocess_driver_semantics(tmp_path):
+    """clip counter counts skipped lines; frame number is 1-based; unopenable clips are skipped"""
+    from cvsd_amd import preprocess_driver as P
+    (tmp_path / "Shoplifting").mkdir()
+    np.save(tmp_path / "Shoplifting" / "Shoplifting003_x264.npy", np.zeros((3, 8, 8, 3), np.uint8))
+    lst = tmp_path / "list.txt"
+    lst.write_text("Abuse/Abuse001_x264.mp4\nShoplifting/Shoplifting003_x264.mp4\nShoplifting/Missing_x264.mp4")
+    calls = []
+
+    class T:
+        def save_to_dataset(self, frame, i, n, label, name):
+            calls.append((i, n, label, name, frame.shape))
+    logs = []
+    n = P.run(T(), str(lst), str(tmp_path) + "/", capture=P.NpyCapture, log=logs.append)
+    assert n == 3
+    assert calls == [(2, float(k), "Shoplifting", "Shoplifting003_x264.mp4", (8, 8, 3)) for k in (1, 2, 3)]
+    assert any("Failed to load video" in m for m in logs) and any("Skipping, Abuse" in m for m in logs)
+
+
+def test_tracker_assigns_stable_ids():
+    from cvsd_amd.tracker import BYTETracker
+    tr = BYTETracker()
+    det = np.array([[10, 10, 50, 90, 0.9, 0], [200, 40, 260, 160, 0.8, 0]], np.float32)
+    out1 = tr.update(det)
+    assert out1.shape == (2, 8) and sorted(out1[:, 4].tolist()) == [1.0, 2.0]
+    ids = {tuple(np.round(r[:2] / 50)): r[4] for r in out1}
+    for step in range(1, 5):
+        moved = det.copy()
+        moved[:, [0, 2]] += 3 * step
+        out = tr.update(moved[::-1].copy())                      # detection order must not matter
+        assert out.shape == (2, 8)
+        for r in out:
+            assert ids[tuple(np.round((r[:2] - 3 * step) / 50))] == r[4]
+    assert tr.update(np.zeros((0, 6), np.float32)).shape == (0, 8)
