@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 namespace mi355 {
 
@@ -37,6 +38,7 @@ struct ConvKArgs {
 // search) is done once per (op, shape) by the engine; run_conv only enqueues.
 struct ConvLaunch { const void* fn; unsigned grid_x, grid_y; size_t lds; ConvKArgs a; int CT, WP; double flops; };
 const char* plan_conv(const ConvArgs& c, ConvLaunch* out);
+const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out);   // best static guess first
 const char* run_conv(const ConvLaunch& l, hipStream_t st);
 
 // ---- misc kernels, misc_kernels.hip ---------------------------------------------------------------------
@@ -73,8 +75,10 @@ struct DecodeArgs {
     int B, A, nc, nkpt, kdim;
     float* pred;        // [B][A][no] anchor-major decoded tensor (xywh, scores, kpts), no = 4+nc+nkpt*kdim
     float2* best;       // [B][A] (best score, best class as float)
+    int tile0[4]; int tiles_per_image;   // filled by launch_decode
 };
-const char* launch_decode(const DecodeArgs& a, hipStream_t st);
+// full = also store the nc class scores into pred (raw-head entry point); NMS itself only needs box/kpts/best
+const char* launch_decode(const DecodeArgs& a, bool full, hipStream_t st);
 // pred in Ultralytics layout [B][no][A] -> anchor-major [B][A][no] plus best[]; used by mi355_op_nms
 const char* launch_best_from_pred(const float* pred_anchor_major, int B, int A, int no, int nc, float2* best,
                                   hipStream_t st);

@@ -16,6 +16,13 @@
 // x CT cout tiles of 16x16.  The input tile (with halo) is staged through LDS in chunks of `ck` channels.
 #include "common.h"
 #include "detmath.h"
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+#include <type_traits>
+#ifndef MI355_CONV_WAVES
+#define MI355_CONV_WAVES 3   // min waves per SIMD the register allocator must leave room for (4 blocks of 256 threads / CU = 4)
+#endif
 
 #pragma clang fp contract(off)
 
@@ -78,28 +85,53 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
         const int rem = a.Cin - c0;
         const int nkk = ((rem < a.ck ? rem : a.ck) + 15) >> 4;
         const int cib0 = c0 >> 4;
-        // canonical accumulation order of one output: 16-channel block (outer), tap, MFMA step s, k-group g
-        for (int kk = 0; kk < nkk; ++kk) {
+        // canonical accumulation order of one output: 16-channel block (outer), tap, MFMA step s, k-group g.
+        // (block, tap) is flattened into one runtime loop of pipeline steps; all offsets advance as wave-uniform
+        // scalars.  Two static register sets: the fragments of step i+1 are in flight while step i's MFMAs issue.
+        const int n_it = nkk * TAPS;
+        int l_kw = 0, l_kh = 0, l_kk = 0;
+        int l_xoff = 0;                                   // (kh*TWin + kw)*ldp + kk*16   (floats, LDS)
+        int l_woff = cib0 * 256;                          // (tap*cib + cib0 + kk)*256    (floats, packed weights)
+        const int wstep = a.cib * 256;
+        f32x4 wf0[CT], xf0[PT], wf1[CT], xf1[PT];
+        auto load_frags = [&](f32x4* wf, f32x4* xf) {
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                const int tapoff = ((tap / KS) * a.TWin + (tap % KS)) * a.ldp;
-                f32x4 wf[CT], xf[PT];
+            for (int ct = 0; ct < CT; ++ct) {
+                const int ctile = ct0 + ct;
+                wf[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (ctile < a.n_ctiles)
+                    wf[ct] = *(const f32x4*)(a.wpk + (size_t)ctile * TAPS * wstep + l_woff + lane * 4);
+            }
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const int ctile = ct0 + ct;
-                    wf[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (ctile < a.n_ctiles)
-                        wf[ct] = *(const f32x4*)(a.wpk + ((size_t)(ctile * TAPS + tap) * a.cib + cib0 + kk) * 256 + lane * 4);
-                }
+            for (int pt = 0; pt < PT; ++pt) xf[pt] = *(const f32x4*)(lds + xoff[pt] + l_xoff);
+            // advance to the next step: kw, then kh, then the next 16-channel block
+            ++l_kw; l_xoff += a.ldp; l_woff += wstep;
+            if (l_kw == KS) {
+                l_kw = 0; ++l_kh; l_xoff += (a.TWin - KS) * a.ldp;
+                if (l_kh == KS) { l_kh = 0; ++l_kk; l_xoff = l_kk * 16; l_woff = (cib0 + l_kk) * 256; }
+            }
+        };
+        auto mma = [&](const f32x4* wf, const f32x4* xf) {
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) xf[pt] = *(const f32x4*)(lds + xoff[pt] + tapoff + kk * 16);
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                        for (int pt = 0; pt < PT; ++pt)
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][s], xf[pt][s], acc[ct][pt], 0, 0, 0);
+                    for (int pt = 0; pt < PT; ++pt)
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][s], xf[pt][s], acc[ct][pt], 0, 0, 0);
+        };
+        load_frags(wf0, xf0);
+        for (int it = 0; it < n_it; it += 2) {
+            const bool has1 = it + 1 < n_it;
+            if (has1) load_frags(wf1, xf1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(wf0, xf0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has1) {
+                if (it + 2 < n_it) load_frags(wf0, xf0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(wf1, xf1);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -183,44 +215,63 @@ KernelFn pick_kernel(int ks, int stride, int CT, int WP) {
     return nullptr;
 }
 
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 constexpr size_t LDS_SOFT = 40 * 1024, LDS_HARD = 64 * 1024;
 
-// choose the wave arrangement, the output tile and the staged channel count for one conv
-Plan make_plan(int H, int W, int n_ctiles, int cin, int ks, int stride) {
-    Plan best{}; best.cost = 1e30;
+// Candidate launch plans for one conv: for every wave arrangement (CT, WC) the best output tile, with every
+// feasible staged-channel count.  Sorted by a static cost model; the engine may time the first few (autotune).
+std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, int stride) {
+    static const int max_ct = env_int("MI355_MAX_CT", 5);          // tuning knobs (experiments only)
+    static const int min_wc = env_int("MI355_MIN_WC", 1);
+    std::vector<Plan> out;
     const int cin16 = round_up(cin, 16);
     for (int WC = 1; WC <= 4; WC *= 2)
         for (int CT = 1; CT <= 5; ++CT) {
+            if (CT > max_ct || WC < min_wc) continue;
             const int WP = 4 / WC, PT = (CT == 5 ? 3 : 4), P = WP * PT * 16;
             const int cover = CT * WC, nblk = (n_ctiles + cover - 1) / cover;
+            if (cover >= 2 * n_ctiles && cover > CT) continue;          // more than half of the cout tiles would be padding
             const double waste_c = (double)nblk * cover / n_ctiles;
-            for (int TW = 1; TW <= P && TW <= W; ++TW) {
-                int TH = P / TW; if (TH > H) TH = H;
-                if (TH < 1) continue;
-                const long tiles = (long)((W + TW - 1) / TW) * ((H + TH - 1) / TH);
-                const int THin = (TH - 1) * stride + ks, TWin = (TW - 1) * stride + ks;
-                const size_t lds16 = (size_t)THin * TWin * (16 + 4) * 4;
-                if (lds16 > LDS_HARD) continue;
-                int ck = 16;
-                for (int c = 64; c >= 16; c >>= 1)
-                    if (c <= cin16 && (size_t)THin * TWin * (c + 4) * 4 <= LDS_SOFT) { ck = c; break; }
-                const double infl = waste_c * (double)tiles * P / ((double)W * H);
-                const double halo = (double)THin * TWin / ((double)TH * TW * stride * stride);
-                double cost = infl * (1.0 + 0.03 * halo * nblk) + (lds16 > LDS_SOFT ? 0.3 : 0.0) - 0.002 * CT;
-                if (cost < best.cost) best = Plan{CT, WP, TW, TH, ck, (size_t)THin * TWin * (ck + 4) * 4, cost};
+            for (int ck = 64; ck >= 16; ck >>= 1) {
+                if (ck > cin16 && ck != 16) continue;
+                Plan best{}; best.cost = 1e30;
+                for (int TW = 1; TW <= P && TW <= W; ++TW) {
+                    int TH = P / TW; if (TH > H) TH = H;
+                    if (TH < 1) continue;
+                    const long tiles = (long)((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+                    const int THin = (TH - 1) * stride + ks, TWin = (TW - 1) * stride + ks;
+                    const size_t lds = (size_t)THin * TWin * (ck + 4) * 4;
+                    if (lds > LDS_HARD) continue;
+                    const double infl = waste_c * (double)tiles * P / ((double)W * H);
+                    const double halo = (double)THin * TWin / ((double)TH * TW * stride * stride);
+                    const int stages = (cin16 + ck - 1) / ck;
+                    double cost = infl * (1.0 + 0.03 * halo * nblk) * (1.0 + 0.04 * (stages - 1)) * (1.0 + 0.04 * (CT - 1))
+                                  + (lds > LDS_SOFT ? 0.15 : 0.0);
+                    if (cost < best.cost) best = Plan{CT, WP, TW, TH, ck, lds, cost};
+                }
+                if (best.cost < 1e30) out.push_back(best);
             }
         }
-    return best;
+    std::sort(out.begin(), out.end(), [](const Plan& a, const Plan& b) { return a.cost < b.cost; });
+    return out;
 }
 
 }  // namespace
 
-const char* plan_conv(const ConvArgs& c, ConvLaunch* out) {
+static const char* check_args(const ConvArgs& c) {
     if (!((c.k == 1 && c.stride == 1) || (c.k == 3 && (c.stride == 1 || c.stride == 2))))
         return "conv: only 1x1/s1, 3x3/s1 and 3x3/s2 are supported";
     if ((c.src_cs & 3) || (c.dst_cs & 3) || (c.res && (c.res_cs & 3))) return "conv: channel strides must be multiples of 4";
     if (((uintptr_t)c.src | (uintptr_t)c.dst | (uintptr_t)c.res | (uintptr_t)c.wpk | (uintptr_t)c.bias) & 15)
         return "conv: pointers must be 16-byte aligned";
+    return nullptr;
+}
+
+static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* out) {
     ConvKArgs a{};
     a.src = c.src; a.dst = c.dst; a.res = c.res; a.wpk = c.wpk; a.bias = c.bias;
     a.src_cs = c.src_cs; a.dst_cs = c.dst_cs; a.res_cs = c.res_cs;
@@ -232,8 +283,6 @@ const char* plan_conv(const ConvArgs& c, ConvLaunch* out) {
     } else {
         a.Hin = c.Hin; a.Win = c.Win; a.Hout = c.Hout; a.Wout = c.Wout;
     }
-    const Plan p = make_plan(a.Hout, a.Wout, a.n_ctiles, c.Cin, c.k, c.stride);
-    if (p.cost >= 1e30) return "conv: no launch plan fits in LDS";
     KernelFn fn = pick_kernel(c.k, c.stride, p.CT, p.WP);
     if (!fn) return "conv: no kernel instance";
     a.TW = p.TW; a.TH = p.TH;
@@ -252,6 +301,27 @@ const char* plan_conv(const ConvArgs& c, ConvLaunch* out) {
     out->a = a;
     out->CT = p.CT; out->WP = p.WP;
     out->flops = 2.0 * c.B * c.Hout * c.Wout * (double)c.Cout * c.Cin * c.k * c.k;
+    return nullptr;
+}
+
+// all candidate launches for one conv, best static guess first
+const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out) {
+    if (const char* e = check_args(c)) return e;
+    const int H = c.k == 1 ? 1 : c.Hout, W = c.k == 1 ? c.B * c.Hout * c.Wout : c.Wout;
+    const std::vector<Plan> plans = enumerate_plans(H, W, (c.Cout + 15) / 16, c.Cin, c.k, c.stride);
+    if (plans.empty()) return "conv: no launch plan fits in LDS";
+    for (const Plan& p : plans) {
+        ConvLaunch l{};
+        if (const char* e = build_launch(c, p, &l)) return e;
+        out->push_back(l);
+    }
+    return nullptr;
+}
+
+const char* plan_conv(const ConvArgs& c, ConvLaunch* out) {
+    std::vector<ConvLaunch> v;
+    if (const char* e = plan_conv_candidates(c, &v)) return e;
+    *out = v[0];
     return nullptr;
 }
 

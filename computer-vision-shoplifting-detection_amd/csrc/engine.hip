@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -111,7 +112,8 @@ struct mi355_yolo {
     std::vector<FileLevel> levels;
     std::vector<DevConv> dconv;
     float* lut = nullptr;
-    int chunk = 16;
+    int chunk = 64;
+    int autotune = 12;                  // candidate launch plans timed per conv when a shape is first seen (0 = off)
     long long n_params = 0, macs640 = 0;
 
     // per-shape state
@@ -259,7 +261,28 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
         a.B = nb; a.Hin = Hl / sd_in; a.Win = Wl / sd_in; a.Hout = Hl / sd_out; a.Wout = Wl / sd_out;
         a.Cin = c.cin; a.Cout = c.cout; a.k = c.k; a.stride = c.s; a.pad = c.pad; a.act = c.act;
         if (a.Hout * (int)c.s != a.Hin || a.Wout * (int)c.s != a.Win) return fail(MI355_EFORMAT, "conv resolution mismatch in program");
-        KCHK(plan_conv(a, &h->plans[i]));
+        std::vector<ConvLaunch> cands;
+        KCHK(plan_conv_candidates(a, &cands));
+        h->plans[i] = cands[0];
+        if (h->autotune && cands.size() > 1) {
+            // Time the most promising launch plans on the real buffers (outputs are overwritten by the next real
+            // pass; the accumulation order is plan-independent, so the choice cannot change results).
+            const size_t ncand = std::min<size_t>(cands.size(), (size_t)h->autotune);
+            float best_ms = 1e30f;
+            for (size_t k = 0; k < ncand; ++k) {
+                float ms = 1e30f;
+                for (int rep = 0; rep < 3; ++rep) {
+                    HIPCHK(hipEventRecord(h->ev0, h->stream));
+                    KCHK(run_conv(cands[k], h->stream));
+                    HIPCHK(hipEventRecord(h->ev1, h->stream));
+                    HIPCHK(hipEventSynchronize(h->ev1));
+                    float t = 0.f;
+                    HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
+                    if (rep > 0) ms = std::min(ms, t);          // first run warms the instruction cache
+                }
+                if (ms < best_ms) { best_ms = ms; h->plans[i] = cands[k]; }
+            }
+        }
     }
     int A = 0;
     for (const FileLevel& lv : h->levels) A += (Hl / lv.stride) * (Wl / lv.stride);
@@ -290,7 +313,7 @@ struct Prof {
 };
 
 // run the net (+decode) on nb frames that sit in `frames_dev` (original size h0 x w0, dense)
-static int run_chunk(mi355_yolo* h, Prof& pf, const uint8_t* frames_dev, int nb, const Geometry& g) {
+static int run_chunk(mi355_yolo* h, Prof& pf, const uint8_t* frames_dev, int nb, const Geometry& g, bool full_pred) {
     const uint8_t* stem_in = frames_dev;
     if (!g.identity) {
         LetterboxArgs la{};
@@ -359,7 +382,7 @@ static int run_chunk(mi355_yolo* h, Prof& pf, const uint8_t* frames_dev, int nb,
     d.B = nb; d.A = h->A; d.nc = h->hdr.nc; d.nkpt = h->hdr.nkpt; d.kdim = h->hdr.kdim;
     d.pred = h->pred; d.best = h->best;
     if (pf.begin(K_DECODE)) return fail(MI355_EHIP, "event");
-    KCHK(launch_decode(d, h->stream));
+    KCHK(launch_decode(d, full_pred, h->stream));
     pf.end();
     return MI355_OK;
 }
@@ -465,7 +488,7 @@ static int infer_impl(mi355_yolo* h, const uint8_t* src, bool src_on_device, int
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     for (int s = 0; s < n; s += nb) {
         const int m = std::min(nb, n - s);
-        rc = run_chunk(h, pf, dev_frames + (size_t)s * frame_bytes, m, g); if (rc) return rc;
+        rc = run_chunk(h, pf, dev_frames + (size_t)s * frame_bytes, m, g, false); if (rc) return rc;
         NmsArgs na{};
         na.pred = h->pred; na.best = h->best; na.B = m; na.A = h->A; na.no = h->no(); na.nc = h->hdr.nc;
         na.nk = h->hdr.nkpt * h->hdr.kdim; na.kdim = h->hdr.kdim;
@@ -509,6 +532,7 @@ static int create_impl(const uint8_t* blob, size_t nbytes, int device_id, const 
     std::unique_ptr<mi355_yolo> h(new mi355_yolo());
     h->device = device_id;
     if (opts && opts->struct_size >= (int)sizeof(mi355_opts) && opts->batch_chunk > 0) h->chunk = opts->batch_chunk;
+    if (const char* e = getenv("MI355_AUTOTUNE")) h->autotune = std::max(0, atoi(e));
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
     const int rc = parse_blob(h.get(), blob, nbytes);
@@ -619,7 +643,7 @@ int mi355_yolo_raw_head(mi355_yolo* h, const uint8_t* bgr, int n, int height, in
     const bool was = h->profiling; h->profiling = false;
     for (int s = 0; s < n; s += nb) {
         const int m = std::min(nb, n - s);
-        rc = run_chunk(h, pf, h->d_in + (size_t)s * frame_bytes, m, g);
+        rc = run_chunk(h, pf, h->d_in + (size_t)s * frame_bytes, m, g, true);
         if (rc) { h->profiling = was; return rc; }
         KCHK(launch_transpose_pred(h->pred, h->d_rawhead, m, A, h->no(), h->stream));
         HIPCHK(hipMemcpyAsync(out + (size_t)s * per, h->d_rawhead, per * m * 4, hipMemcpyDeviceToHost, h->stream));

@@ -15,67 +15,143 @@
 namespace mi355 {
 
 // ---------------------------------------------------------------------------------------------- decode
-// One lane per anchor.  Reads the raw head maps (NHWC, per level: 64 box logits | nc class logits | nk kpts)
-// and writes the decoded prediction row [4 + nc + nk] (anchor-major) plus (best score, best class).
-__global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
-    const long total = (long)a.B * a.A;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int an = (int)(i % a.A), b = (int)(i / a.A);
+// Reads the raw head maps (NHWC, per level: 64 box logits | nc class logits | nk kpts) and writes, per anchor, the
+// decoded row [4 box | nc scores | nk kpts] (anchor-major) plus (best score, best class).
+// One lane owns one anchor and evaluates it sequentially (the canonical operation order), but all global traffic
+// is coalesced: a 128-anchor tile of one level is contiguous in NHWC memory, so it is staged through LDS
+// (row pitch odd -> conflict-free per-lane row walks).  FULL = also store the nc sigmoid scores (only the
+// raw-head parity entry point needs them: NMS reads box, keypoints and `best` only), which cuts the kernel's
+// HBM writes from 86 to 6 floats per anchor for an 80-class detector.
+constexpr int DEC_T = 128;
+
+template <bool FULL>
+__global__ __launch_bounds__(DEC_T) void decode_kernel(DecodeArgs a, int pw) {
+    extern __shared__ float tile[];                     // [DEC_T][pw], pw odd and >= max(64, nc, nk)
+    const int tid = threadIdx.x;
+    // block -> (image, level, tile of 128 anchors inside the level)
+    int blk = blockIdx.x;
+    const int tiles_per_img = a.tiles_per_image;
+    const int b = blk / tiles_per_img;
+    blk -= b * tiles_per_img;
     int l = 0;
 #pragma unroll
     for (int j = 1; j < 4; ++j)
-        if (j < a.n_levels && an >= a.lv[j].anchor0) l = j;
+        if (j < a.n_levels && blk >= a.tile0[j]) l = j;
     const HeadLevelArgs lv = a.lv[l];
-    const int li = an - lv.anchor0;
-    const int y = li / lv.W, x = li - y * lv.W;
-    const float* p = lv.buf + (((size_t)b * lv.H + y) * lv.W + x) * lv.cs;
-    const float ax = (float)x + 0.5f, ay = (float)y + 0.5f, st = (float)lv.stride;
+    const int hw = lv.H * lv.W;
+    const int li0 = (blk - a.tile0[l]) * DEC_T;         // first anchor of this tile within the level
+    const int n_here = min(DEC_T, hw - li0);
+    const float* src = lv.buf + ((size_t)b * hw + li0) * lv.cs;     // n_here consecutive pixels, lv.cs floats each
     const int nk = a.nkpt * a.kdim, no = 4 + a.nc + nk;
-    float* out = a.pred + (size_t)i * no;
+    const int li = li0 + tid;
+    const bool live = tid < n_here;
+    const int y = live ? li / lv.W : 0, x = live ? li - y * lv.W : 0;
+    const float ax = (float)x + 0.5f, ay = (float)y + 0.5f, st = (float)lv.stride;
+    const size_t row = (size_t)b * a.A + lv.anchor0 + li;
+    float* out = a.pred + row * no;
 
-    float dist[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const float4* q = (const float4*)(p + lv.box_off + 16 * s);
-        float v[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const float4 t = q[j]; v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w; }
-        float m = v[0];
-#pragma unroll
-        for (int j = 1; j < 16; ++j) m = fmaxf(m, v[j]);
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { v[j] = det_expf(v[j] - m); sum += v[j]; }
-        float d = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) d += (v[j] / sum) * (float)j;
-        dist[s] = d;
+    // ---- box: 64 logits per anchor
+    for (int i = tid; i < n_here * 16; i += DEC_T) {
+        const int r = i >> 4, q = i & 15;
+        const float4 v = *(const float4*)(src + (size_t)r * lv.cs + lv.box_off + 4 * q);
+        float* t = tile + r * pw + 4 * q;
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
     }
-    const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
-    out[0] = ((x1 + x2) / 2.0f) * st;
-    out[1] = ((y1 + y2) / 2.0f) * st;
-    out[2] = (x2 - x1) * st;
-    out[3] = (y2 - y1) * st;
-    float best = -1.f; int bi = 0;
-    for (int c = 0; c < a.nc; ++c) {
-        const float s = det_sigmoid(p[lv.cls_off + c]);
-        out[4 + c] = s;
-        if (s > best) { best = s; bi = c; }
+    __syncthreads();
+    if (live) {
+        const float* t = tile + tid * pw;
+        float dist[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = t[16 * s + j];
+            float m = v[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) m = fmaxf(m, v[j]);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { v[j] = det_expf(v[j] - m); sum += v[j]; }
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) d += (v[j] / sum) * (float)j;
+            dist[s] = d;
+        }
+        const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
+        float4 o;
+        o.x = ((x1 + x2) / 2.0f) * st;
+        o.y = ((y1 + y2) / 2.0f) * st;
+        o.z = (x2 - x1) * st;
+        o.w = (y2 - y1) * st;
+        if ((no & 3) == 0) *(float4*)out = o;           // rows are 16-byte aligned when 4 + nc + nk is a multiple of 4
+        else { out[0] = o.x; out[1] = o.y; out[2] = o.z; out[3] = o.w; }
     }
-    a.best[i] = make_float2(best, (float)bi);
-    for (int k = 0; k < a.nkpt; ++k) {
-        const float* kp = p + lv.kpt_off + k * a.kdim;
-        float* ko = out + 4 + a.nc + k * a.kdim;
-        ko[0] = (kp[0] * 2.0f + (ax - 0.5f)) * st;
-        ko[1] = (kp[1] * 2.0f + (ay - 0.5f)) * st;
-        if (a.kdim == 3) ko[2] = det_sigmoid(kp[2]);
+    __syncthreads();
+    // ---- class scores
+    for (int i = tid; i < n_here * a.nc; i += DEC_T) {
+        const int r = i / a.nc, c = i - r * a.nc;
+        tile[r * pw + c] = src[(size_t)r * lv.cs + lv.cls_off + c];
+    }
+    __syncthreads();
+    if (live) {
+        float* t = tile + tid * pw;
+        float best = -1.f; int bi = 0;
+        for (int c = 0; c < a.nc; ++c) {
+            const float s = det_sigmoid(t[c]);
+            if (FULL) t[c] = s;
+            if (s > best) { best = s; bi = c; }
+        }
+        a.best[row] = make_float2(best, (float)bi);
+    }
+    if (FULL) {
+        __syncthreads();
+        float* o = a.pred + ((size_t)b * a.A + lv.anchor0 + li0) * no;
+        for (int i = tid; i < n_here * a.nc; i += DEC_T) {
+            const int r = i / a.nc, c = i - r * a.nc;
+            o[(size_t)r * no + 4 + c] = tile[r * pw + c];
+        }
+    }
+    if (nk == 0) return;
+    // ---- keypoints
+    __syncthreads();
+    for (int i = tid; i < n_here * nk; i += DEC_T) {
+        const int r = i / nk, c = i - r * nk;
+        tile[r * pw + c] = src[(size_t)r * lv.cs + lv.kpt_off + c];
+    }
+    __syncthreads();
+    if (live) {
+        float* t = tile + tid * pw;
+        for (int k = 0; k < a.nkpt; ++k) {
+            float* kp = t + k * a.kdim;
+            kp[0] = (kp[0] * 2.0f + (ax - 0.5f)) * st;
+            kp[1] = (kp[1] * 2.0f + (ay - 0.5f)) * st;
+            if (a.kdim == 3) kp[2] = det_sigmoid(kp[2]);
+        }
+    }
+    __syncthreads();
+    {
+        float* o = a.pred + ((size_t)b * a.A + lv.anchor0 + li0) * no;
+        for (int i = tid; i < n_here * nk; i += DEC_T) {
+            const int r = i / nk, c = i - r * nk;
+            o[(size_t)r * no + 4 + a.nc + c] = tile[r * pw + c];
+        }
     }
 }
 
-const char* launch_decode(const DecodeArgs& a, hipStream_t st) {
-    const long total = (long)a.B * a.A;
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+const char* launch_decode(const DecodeArgs& a0, bool full, hipStream_t st) {
+    DecodeArgs a = a0;
+    const int nk = a.nkpt * a.kdim;
+    int t = 0;
+    for (int l = 0; l < a.n_levels; ++l) { a.tile0[l] = t; t += (a.lv[l].H * a.lv[l].W + DEC_T - 1) / DEC_T; }
+    a.tiles_per_image = t;
+    int pw = 64;
+    if (a.nc > pw) pw = a.nc;
+    if (nk > pw) pw = nk;
+    pw |= 1;
+    const size_t lds = (size_t)DEC_T * pw * sizeof(float);
+    const dim3 grid((unsigned)(a.B * t));
+    if (full) hipLaunchKernelGGL(decode_kernel<true>, grid, dim3(DEC_T), lds, st, a, pw);
+    else      hipLaunchKernelGGL(decode_kernel<false>, grid, dim3(DEC_T), lds, st, a, pw);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

@@ -46,7 +46,7 @@ typedef struct mi355_yolo mi355_yolo;   /* opaque engine handle */
 /* Engine options; zero-initialise and set struct_size = sizeof(mi355_opts). 0 means "default". */
 typedef struct mi355_opts {
     int struct_size;
-    int batch_chunk;      /* frames pushed through the net per pass (default 16); larger batches are looped */
+    int batch_chunk;      /* frames pushed through the net per pass (default 64); larger batches are looped */
     int reserved[6];
 } mi355_opts;
 
