@@ -18,62 +18,82 @@ __device__ __forceinline__ float silu_m(float v) { return det_silu(v); }
 // (16-byte store); the Cout/4 lanes of a pixel sit next to each other so a wave writes contiguous memory.
 // Direct conv on the vector ALUs: K = 27 (or 108) is far too shallow for the matrix pipe and the layer is
 // HBM-write bound (16-48 floats out per 27 bytes in).
+constexpr int STEM_TO = 16;        // output tile 16 x 16 pixels per block
+
 template <int KS>
 __global__ __launch_bounds__(256) void stem_conv_u8(StemArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [KS*KS*3][Cout4] then lut[256]
+    // LDS: weights [KS*KS*3][Cout4] | lut[256] | input tile [TIN][TIN][3] already converted to float (0 outside the image:
+    // fmaf(0, w, acc) == acc exactly, so zero-filling equals skipping the tap)
+    extern __shared__ __attribute__((aligned(16))) float wl[];
     const int cq = (a.Cout + 3) >> 2, cout4 = cq << 2;
+    const int TIN = (STEM_TO - 1) * a.stride + KS;
     float* lut = wl + KS * KS * 3 * cout4;
-    for (int i = threadIdx.x; i < KS * KS * 3 * cout4; i += blockDim.x) {
+    float* tin = lut + 256;
+    for (int i = threadIdx.x; i < KS * KS * 3 * cout4; i += 256) {
         const int co = i % cout4, r = i / cout4;       // r = tap*3 + byte channel (B,G,R)
         const int cb = r % 3, tap = r / 3;
         // byte channel cb (0=B,1=G,2=R) feeds model channel 2-cb (im[..., ::-1])
         wl[i] = co < a.Cout ? a.w[((size_t)co * 3 + (2 - cb)) * (KS * KS) + tap] : 0.f;
     }
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) lut[i] = a.lut[i];
-    __syncthreads();
-    const int ppb = blockDim.x / cq;                   // pixels per block
-    const int q = threadIdx.x % cq, lp = threadIdx.x / cq;
-    if (lp >= ppb) return;
-    const long total = (long)a.B * a.Hout * a.Wout;
-    const long pix = (long)blockIdx.x * ppb + lp;
-    if (pix >= total) return;
-    const int ox = (int)(pix % a.Wout);
-    const int oy = (int)((pix / a.Wout) % a.Hout);
-    const int b = (int)(pix / ((long)a.Wout * a.Hout));
+    lut[threadIdx.x] = a.lut[threadIdx.x];
+    const int tiles_x = (a.Wout + STEM_TO - 1) / STEM_TO, tiles_y = (a.Hout + STEM_TO - 1) / STEM_TO;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int oy0 = ty * STEM_TO, ox0 = tx * STEM_TO;
+    const int iy0 = oy0 * a.stride - a.pad, ix0 = ox0 * a.stride - a.pad;
     const uint8_t* img = a.img + (size_t)b * a.H * a.W * 3;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int i = threadIdx.x; i < TIN * TIN * 3; i += 256) {
+        const int c = i % 3, p = i / 3;
+        const int ix = p % TIN, iy = p / TIN;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        float v = 0.f;
+        if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) v = lut[img[((size_t)gy * a.W + gx) * 3 + c]];
+        tin[i] = v;
+    }
+    __syncthreads();
+    for (int item = threadIdx.x; item < STEM_TO * STEM_TO * cq; item += 256) {
+        const int q = item % cq, lp = item / cq;
+        const int lx = lp % STEM_TO, ly = lp / STEM_TO;
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        if (oy >= a.Hout || ox >= a.Wout) continue;
+        const float* xin = tin + ((ly * a.stride) * TIN + lx * a.stride) * 3;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kh = 0; kh < KS; ++kh) {
-        const int y = oy * a.stride - a.pad + kh;
-        if ((unsigned)y >= (unsigned)a.H) continue;
+        for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < KS; ++kw) {
-            const int x = ox * a.stride - a.pad + kw;
-            if ((unsigned)x >= (unsigned)a.W) continue;
-            const uint8_t* px = img + ((size_t)y * a.W + x) * 3;
-            const float* wr = wl + ((kh * KS + kw) * 3) * cout4 + 4 * q;
+            for (int kw = 0; kw < KS; ++kw) {
+                const float* wr = wl + ((kh * KS + kw) * 3) * cout4 + 4 * q;
 #pragma unroll
-            for (int cb = 0; cb < 3; ++cb) {
-                const float v = lut[px[cb]];
-                const f32x4 w4 = *(const f32x4*)(wr + cb * cout4);
+                for (int cb = 0; cb < 3; ++cb) {
+                    const float v = xin[(kh * TIN + kw) * 3 + cb];
+                    const f32x4 w4 = *(const f32x4*)(wr + cb * cout4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(v, w4[j], acc[j]);   // canonical chain: kh, kw, (B,G,R)
+                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(v, w4[j], acc[j]);   // canonical chain: kh, kw, (B,G,R)
+                }
             }
+        const int c = 4 * q;
+        float* d = a.dst + (((size_t)b * a.Hout + oy) * a.Wout + ox) * a.dst_cs + c;
+        if (c + 3 < a.Cout) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = silu_m(acc[j] + a.bias[c + j]);
+            *(f32x4*)d = o;
+        } else {
+            for (int j = 0; j < 4 && c + j < a.Cout; ++j) d[j] = silu_m(acc[j] + a.bias[c + j]);
         }
     }
-    const int c = 4 * q;
-    float* d = a.dst + (size_t)pix * a.dst_cs + c;
-    for (int i = 0; i < 4 && c + i < a.Cout; ++i) d[i] = silu_m(acc[i] + a.bias[c + i]);
 }
 
 const char* launch_stem(const StemArgs& a, hipStream_t st) {
     if (a.k != 3 && a.k != 6) return "stem: only 3x3 and 6x6 stems are supported";
     const int cq = (a.Cout + 3) / 4;
-    if (cq > 256) return "stem: too many output channels";
-    const int ppb = 256 / cq;
-    const long total = (long)a.B * a.Hout * a.Wout;
-    const unsigned grid = (unsigned)((total + ppb - 1) / ppb);
-    const size_t lds = ((size_t)a.k * a.k * 3 * cq * 4 + 256) * sizeof(float);
+    const int tin = (STEM_TO - 1) * a.stride + a.k;
+    const size_t lds = ((size_t)a.k * a.k * 3 * cq * 4 + 256 + (size_t)tin * tin * 3) * sizeof(float);
+    if (lds > 64 * 1024) return "stem: tile does not fit in LDS";
+    const unsigned grid = (unsigned)((long)a.B * ((a.Wout + STEM_TO - 1) / STEM_TO) * ((a.Hout + STEM_TO - 1) / STEM_TO));
     if (a.k == 3) hipLaunchKernelGGL(stem_conv_u8<3>, dim3(grid), dim3(256), lds, st, a);
     else          hipLaunchKernelGGL(stem_conv_u8<6>, dim3(grid), dim3(256), lds, st, a);
     hipError_t e = hipGetLastError();

@@ -209,3 +209,24 @@ def test_track_call_of_the_reference(v8n):
             seen += 1
             assert boxes.data.shape[1] == 7 and float(boxes[0].id) >= 1 and boxes.xywhn.shape[1] == 4
     assert seen >= 1
+
+
+@pytest.mark.parametrize("name,n,h,w,imgsz", [
+    ("yolov8s-pose", 2, 320, 320, 320),     # config 4's model
+    ("yolov8m", 1, 256, 320, 320),          # config 5's model: widths 48/96/192/384/576, deeper C2f
+    ("yolov5nu", 2, 320, 320, 320),         # the reference's literal family (yolov5mu.pt): C3 blocks + 6x6 stem
+    ("yolov8n", 1, 1280, 1280, 1280),       # 33600 anchors: > 32768 sort keys, global-memory bitonic path
+])
+def test_bit_exact_other_models_and_sizes(name, n, h, w, imgsz):
+    from oracle import det
+    from tools import synth
+    ckpt = synth.synthetic_checkpoint(name, seed=0)
+    m = _model(name, ckpt)
+    dm = det.DetOracleModel(name, ckpt[1])
+    frames = synth.synthetic_frames(n, h, w, seed=31)
+    want, pred = det.predict(dm, list(frames), conf=0.25, imgsz=imgsz)
+    np.testing.assert_array_equal(m.raw_head(frames, imgsz=imgsz), pred.numpy())
+    _assert_rows_identical(m.predict(frames, conf=0.25, imgsz=imgsz), want, dm.pose)
+    # low threshold: thousands of candidates per image through sort + greedy NMS, max_det cap
+    want, _ = det.predict(dm, list(frames[:1]), conf=0.001, imgsz=imgsz)
+    _assert_rows_identical(m.predict(frames[:1], conf=0.001, imgsz=imgsz), want, dm.pose)
