@@ -19,6 +19,7 @@ struct ConvArgs {
     int B, Hin, Win, Hout, Wout;
     int Cin, Cout;
     int k, stride, pad, act;           // k in {1,3}; act: 0 none, 1 SiLU
+    const float* zeros;                // device pointer to >= 16 zero bytes, or nullptr (then only v1 plans are offered)
 };
 // number of floats pack_conv_weights writes: ceil(cout/16) * k*k * ceil(cin/16) * 256
 size_t packed_weight_floats(int cout, int cin, int k);
@@ -33,10 +34,12 @@ struct ConvKArgs {
     int TW, TH, tiles_x, tiles_y, TWin, npix_in;
     float inv_TW, inv_TWin;
     int pad, act;
+    const float* zeros;        // >= 16 bytes of zeros (source of out-of-image / beyond-Cin slots of the v2 LDS-DMA loader)
+    int lds_buf_floats;        // v2: floats per LDS stage buffer
 };
 // A planned launch: kernel instance, grid, LDS bytes and kernel arguments.  Planning (tile / wave-arrangement
 // search) is done once per (op, shape) by the engine; run_conv only enqueues.
-struct ConvLaunch { const void* fn; unsigned grid_x, grid_y; size_t lds; ConvKArgs a; int CT, WP; double flops; };
+struct ConvLaunch { const void* fn; unsigned grid_x, grid_y; size_t lds; ConvKArgs a; int CT, WP; double flops; int threads; int version; };
 const char* plan_conv(const ConvArgs& c, ConvLaunch* out);
 const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out);   // best static guess first
 const char* run_conv(const ConvLaunch& l, hipStream_t st);

@@ -33,110 +33,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_f(float v) { return det_silu(v); }
 
-template <int KS, int STRIDE, int PT, int CT, int WP>
-__global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int WC = 4 / WP;
-    constexpr int TAPS = KS * KS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wp = wave % WP, wc = wave / WP;
-    int t = blockIdx.x;
-    const int tx = t % a.tiles_x; t /= a.tiles_x;
-    const int ty = t % a.tiles_y;
-    const int b = t / a.tiles_y;
-    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
-    const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
-    const int ct0 = (blockIdx.y * WC + wc) * CT;
-    const int npix = a.TW * a.TH;
-
-    int xoff[PT];
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-        int p = (wp * PT + pt) * 16 + (lane & 15);
-        p = p < npix ? p : 0;
-        const int ly = (int)(((float)p + 0.5f) * a.inv_TW);
-        const int lx = p - ly * a.TW;
-        xoff[pt] = ((ly * STRIDE) * a.TWin + lx * STRIDE) * a.ldp + (lane >> 4) * 4;
-    }
-    f32x4 acc[CT][PT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const float* srcb = a.src + (size_t)b * a.Hin * a.Win * a.src_cs;
-    const int ck4m = (a.ck >> 2) - 1;
-    const int total_f4 = a.npix_in << a.ck4_shift;
-
-    for (int c0 = 0; c0 < a.Cin; c0 += a.ck) {
-        if (c0) __syncthreads();
-        // ---- stage the halo tile, channels [c0, c0+ck), zero-filled outside the image / beyond Cin ----
-        for (int idx = tid; idx < total_f4; idx += 256) {
-            const int pix = idx >> a.ck4_shift, q = idx & ck4m;
-            const int iy = (int)(((float)pix + 0.5f) * a.inv_TWin);
-            const int ix = pix - iy * a.TWin;
-            const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + 4 * q;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && c < a.cin4)
-                v = *(const f32x4*)(srcb + ((size_t)gy * a.Win + gx) * a.src_cs + c);
-            *(f32x4*)(lds + pix * a.ldp + 4 * q) = v;
-        }
-        __syncthreads();
-        const int rem = a.Cin - c0;
-        const int nkk = ((rem < a.ck ? rem : a.ck) + 15) >> 4;
-        const int cib0 = c0 >> 4;
-        // canonical accumulation order of one output: 16-channel block (outer), tap, MFMA step s, k-group g.
-        // (block, tap) is flattened into one runtime loop of pipeline steps; all offsets advance as wave-uniform
-        // scalars.  Two static register sets: the fragments of step i+1 are in flight while step i's MFMAs issue.
-        const int n_it = nkk * TAPS;
-        int l_kw = 0, l_kh = 0, l_kk = 0;
-        int l_xoff = 0;                                   // (kh*TWin + kw)*ldp + kk*16   (floats, LDS)
-        int l_woff = cib0 * 256;                          // (tap*cib + cib0 + kk)*256    (floats, packed weights)
-        const int wstep = a.cib * 256;
-        f32x4 wf0[CT], xf0[PT], wf1[CT], xf1[PT];
-        auto load_frags = [&](f32x4* wf, f32x4* xf) {
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int ctile = ct0 + ct;
-                wf[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (ctile < a.n_ctiles)
-                    wf[ct] = *(const f32x4*)(a.wpk + (size_t)ctile * TAPS * wstep + l_woff + lane * 4);
-            }
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt) xf[pt] = *(const f32x4*)(lds + xoff[pt] + l_xoff);
-            // advance to the next step: kw, then kh, then the next 16-channel block
-            ++l_kw; l_xoff += a.ldp; l_woff += wstep;
-            if (l_kw == KS) {
-                l_kw = 0; ++l_kh; l_xoff += (a.TWin - KS) * a.ldp;
-                if (l_kh == KS) { l_kh = 0; ++l_kk; l_xoff = l_kk * 16; l_woff = (cib0 + l_kk) * 256; }
-            }
-        };
-        auto mma = [&](const f32x4* wf, const f32x4* xf) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                    for (int pt = 0; pt < PT; ++pt)
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][s], xf[pt][s], acc[ct][pt], 0, 0, 0);
-        };
-        load_frags(wf0, xf0);
-        for (int it = 0; it < n_it; it += 2) {
-            const bool has1 = it + 1 < n_it;
-            if (has1) load_frags(wf1, xf1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(wf0, xf0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (has1) {
-                if (it + 2 < n_it) load_frags(wf0, xf0);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(wf1, xf1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-
-    // ---- epilogue: bias + SiLU (+ residual), 4 consecutive couts of one pixel per lane ----
+// bias + SiLU (+ residual) and the 16-byte stores: a lane holds 4 consecutive couts of one pixel per tile
+template <int STRIDE, int PT, int CT, int WP>
+__device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x4 (&acc)[CT][PT], int lane, int wp, int ct0, int b,
+                                              int oy0, int ox0, int npix) {
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int p = (wp * PT + pt) * 16 + (lane & 15);
@@ -169,6 +69,268 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
     }
 }
 
+template <int KS, int STRIDE, int PT, int CT, int WP>
+__global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int WC = 4 / WP;
+    constexpr int TAPS = KS * KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave % WP, wc = wave / WP;
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
+    const int ct0 = (blockIdx.y * WC + wc) * CT;
+    const int npix = a.TW * a.TH;
+
+    int xoff[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        int p = (wp * PT + pt) * 16 + (lane & 15);
+        p = p < npix ? p : 0;
+        const int ly = (int)(((float)p + 0.5f) * a.inv_TW);
+        const int lx = p - ly * a.TW;
+        xoff[pt] = ((ly * STRIDE) * a.TWin + lx * STRIDE) * a.ldp + (lane >> 4) * 4;
+    }
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* srcb = a.src + (size_t)b * a.Hin * a.Win * a.src_cs;
+    // cout tiles beyond the last one re-read the last tile's weights (their outputs are discarded by the epilogue):
+    // no branch around the fragment loads, so hipcc keeps a counted s_waitcnt vmcnt(N) and the prefetch stays in flight
+    const float* wbase[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        wbase[ct] = a.wpk + (size_t)ctile * TAPS * a.cib * 256 + lane * 4;
+    }
+    const int ck4m = (a.ck >> 2) - 1;
+    const int total_f4 = a.npix_in << a.ck4_shift;
+
+    for (int c0 = 0; c0 < a.Cin; c0 += a.ck) {
+        if (c0) __syncthreads();
+        // ---- stage the halo tile, channels [c0, c0+ck), zero-filled outside the image / beyond Cin ----
+        for (int idx = tid; idx < total_f4; idx += 256) {
+            const int pix = idx >> a.ck4_shift, q = idx & ck4m;
+            const int iy = (int)(((float)pix + 0.5f) * a.inv_TWin);
+            const int ix = pix - iy * a.TWin;
+            const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + 4 * q;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && c < a.cin4)
+                v = *(const f32x4*)(srcb + ((size_t)gy * a.Win + gx) * a.src_cs + c);
+            *(f32x4*)(lds + pix * a.ldp + 4 * q) = v;
+        }
+        __syncthreads();
+        const int rem = a.Cin - c0;
+        const int nkk = ((rem < a.ck ? rem : a.ck) + 15) >> 4;
+        const int cib0 = c0 >> 4;
+        // canonical accumulation order of one output: 16-channel block (outer), tap, MFMA step s, k-group g.
+        // (block, tap) is flattened into one runtime loop of pipeline steps; all offsets advance as wave-uniform
+        // scalars.  Two static register sets: the fragments of step i+1 are in flight while step i's MFMAs issue.
+        const int n_it = nkk * TAPS;
+        int l_kw = 0, l_kh = 0, l_kk = 0;
+        int l_xoff = 0;                                   // (kh*TWin + kw)*ldp + kk*16   (floats, LDS)
+        int l_woff = cib0 * 256;                          // (tap*cib + cib0 + kk)*256    (floats, packed weights)
+        const int wstep = a.cib * 256;
+        f32x4 wf0[CT], xf0[PT], wf1[CT], xf1[PT];
+        auto load_frags = [&](f32x4* wf, f32x4* xf) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) wf[ct] = *(const f32x4*)(wbase[ct] + l_woff);      // unconditional: keeps vmcnt counted
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+                xf[pt] = *(const f32x4*)__builtin_assume_aligned(lds + xoff[pt] + l_xoff, 16);
+            // advance to the next step: kw, then kh, then the next 16-channel block
+            ++l_kw; l_xoff += a.ldp; l_woff += wstep;
+            if (l_kw == KS) {
+                l_kw = 0; ++l_kh; l_xoff += (a.TWin - KS) * a.ldp;
+                if (l_kh == KS) { l_kh = 0; ++l_kk; l_xoff = l_kk * 16; l_woff = (cib0 + l_kk) * 256; }
+            }
+        };
+        auto mma = [&](const f32x4* wf, const f32x4* xf) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt)
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][s], xf[pt][s], acc[ct][pt], 0, 0, 0);
+        };
+        load_frags(wf0, xf0);
+        int it = 0;
+        for (; it + 2 < n_it; it += 2) {                 // steady state: unconditional prefetches -> counted vmcnt
+            load_frags(wf1, xf1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(wf0, xf0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(wf0, xf0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(wf1, xf1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (it + 1 < n_it) {                             // two steps left
+            load_frags(wf1, xf1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(wf0, xf0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(wf1, xf1);
+        } else {                                         // one step left
+            mma(wf0, xf0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    conv_epilogue<STRIDE, PT, CT, WP>(a, acc, lane, wp, ct0, b, oy0, ox0, npix);
+}
+
+// ---------------------------------------------------------------------------------------------- v2
+// Same GEMM, same canonical accumulation order, different staging: a 5th wave is a pure LOADER.  It fills the next
+// stage's halo tile with LDS-DMA (global_load_lds_dwordx4: 1 KiB per instruction, no VGPR round trip) into the second
+// LDS buffer while the four compute waves issue MFMAs on the current one, so no compute wave ever waits on an
+// activation load (vmcnt is in-order per wave: the compute waves only have weight-fragment loads in flight).
+// The LDS image is dense [pixel][ck] with the 16-byte slot index XOR-swizzled by the pixel index (applied on the
+// DMA *source* side and on the ds_read_b128 side) so that the 16 lanes of a ds_read_b128 group hit 16 distinct slots.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+__device__ __forceinline__ int lds_swz(int pix, int sshift) {
+    return sshift == 2 ? ((-(pix >> 2)) & 3) : (sshift == 3 ? ((pix >> 1) & 7) : (pix & 15));
+}
+
+template <int KS, int STRIDE, int PT, int CT, int WP>
+__global__ __launch_bounds__(320) void conv_igemm_f32_v2(ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int WC = 4 / WP;
+    constexpr int TAPS = KS * KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = wave == 4;
+    const int wp = wave % WP, wc = (wave & 3) / WP;
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
+    const int ct0 = (blockIdx.y * WC + wc) * CT;
+    const int npix = a.TW * a.TH;
+    const int sshift = a.ck4_shift, S = a.ck >> 2;
+    const int nst = (a.Cin + a.ck - 1) / a.ck;
+    const float* srcb = a.src + (size_t)b * a.Hin * a.Win * a.src_cs;
+    const int pieces = ((a.npix_in << sshift) + 63) >> 6;
+
+    auto issue_stage = [&](int st, float* buf) {           // loader wave only
+        const int c0 = st * a.ck;
+        for (int j = 0; j < pieces; ++j) {
+            const int i = j * 64 + lane;
+            const int pix = i >> sshift;
+            const int q = (i & (S - 1)) ^ lds_swz(pix, sshift);
+            const int iy = (int)(((float)pix + 0.5f) * a.inv_TWin);
+            const int ix = pix - iy * a.TWin;
+            const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + 4 * q;
+            const float* g = a.zeros;
+            if (pix < a.npix_in && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && c < a.cin4)
+                g = srcb + ((size_t)gy * a.Win + gx) * a.src_cs + c;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)(buf + j * 256), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    int pbase[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        int p = (wp * PT + pt) * 16 + (lane & 15);
+        p = p < npix ? p : 0;
+        const int ly = (int)(((float)p + 0.5f) * a.inv_TW);
+        const int lx = p - ly * a.TW;
+        pbase[pt] = (ly * STRIDE) * a.TWin + lx * STRIDE;                  // LDS pixel index of tap (0,0)
+    }
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4;
+    const float* wbase[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        wbase[ct] = a.wpk + (size_t)ctile * TAPS * a.cib * 256 + lane * 4;
+    }
+
+    if (loader) issue_stage(0, lds);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        if (loader) {
+            if (st + 1 < nst) issue_stage(st + 1, lds + ((st + 1) & 1) * a.lds_buf_floats);
+        } else {
+            const float* buf = lds + (st & 1) * a.lds_buf_floats;
+            const int c0 = st * a.ck;
+            const int rem = a.Cin - c0;
+            const int nkk = ((rem < a.ck ? rem : a.ck) + 15) >> 4;
+            const int cib0 = c0 >> 4;
+            const int n_it = nkk * TAPS;
+            int l_kw = 0, l_kh = 0, l_kk = 0;
+            int l_pix = 0;                                    // kh*TWin + kw (LDS pixels)
+            int l_woff = cib0 * 256;
+            const int wstep = a.cib * 256;
+            f32x4 wf0[CT], xf0[PT], wf1[CT], xf1[PT];
+            auto load_frags = [&](f32x4* wf, f32x4* xf) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) wf[ct] = *(const f32x4*)(wbase[ct] + l_woff);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    const int pix = pbase[pt] + l_pix;
+                    xf[pt] = *(const f32x4*)__builtin_assume_aligned(
+                        buf + (pix << (sshift + 2)) + ((((l_kk << 2) + g) ^ lds_swz(pix, sshift)) << 2), 16);
+                }
+                ++l_kw; ++l_pix; l_woff += wstep;
+                if (l_kw == KS) {
+                    l_kw = 0; ++l_kh; l_pix += a.TWin - KS;
+                    if (l_kh == KS) { l_kh = 0; ++l_kk; l_pix = 0; l_woff = (cib0 + l_kk) * 256; }
+                }
+            };
+            auto mma = [&](const f32x4* wf, const f32x4* xf) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt)
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][s], xf[pt][s], acc[ct][pt], 0, 0, 0);
+            };
+            load_frags(wf0, xf0);
+            int it = 0;
+            for (; it + 2 < n_it; it += 2) {
+                load_frags(wf1, xf1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(wf0, xf0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(wf0, xf0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(wf1, xf1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (it + 1 < n_it) {
+                load_frags(wf1, xf1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(wf0, xf0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(wf1, xf1);
+            } else {
+                mma(wf0, xf0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    if (loader) return;
+    conv_epilogue<STRIDE, PT, CT, WP>(a, acc, lane, wp, ct0, b, oy0, ox0, npix);
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 size_t packed_weight_floats(int cout, int cin, int k) {
     return (size_t)((cout + 15) / 16) * k * k * ((cin + 15) / 16) * 256;
@@ -191,12 +353,25 @@ void pack_conv_weights(const float* w, int cout, int cin, int k, float* out) {
 
 namespace {
 
-struct Plan { int CT, WP, TW, TH, ck; size_t lds; double cost; };
+struct Plan { int CT, WP, TW, TH, ck; size_t lds; double cost; int version; int buf_floats; };
 
 typedef void (*KernelFn)(ConvKArgs);
 
 template <int KS, int STRIDE, int CT, int WP>
 KernelFn inst() { return &conv_igemm_f32<KS, STRIDE, (CT == 5 ? 3 : 4), CT, WP>; }
+
+template <int KS, int STRIDE, int CT, int WP>
+KernelFn inst2() { return &conv_igemm_f32_v2<KS, STRIDE, (CT == 5 ? 3 : 4), CT, WP>; }
+
+template <int KS, int STRIDE>
+KernelFn pick_ct_wp2(int CT, int WP) {
+#define MI355_CASE(ct, wp) if (CT == ct && WP == wp) return inst2<KS, STRIDE, ct, wp>();
+    MI355_CASE(1, 4) MI355_CASE(2, 4) MI355_CASE(3, 4) MI355_CASE(4, 4) MI355_CASE(5, 4)
+    MI355_CASE(1, 2) MI355_CASE(2, 2) MI355_CASE(3, 2) MI355_CASE(4, 2) MI355_CASE(5, 2)
+    MI355_CASE(1, 1) MI355_CASE(2, 1) MI355_CASE(3, 1) MI355_CASE(4, 1) MI355_CASE(5, 1)
+#undef MI355_CASE
+    return nullptr;
+}
 
 template <int KS, int STRIDE>
 KernelFn pick_ct_wp(int CT, int WP) {
@@ -208,7 +383,13 @@ KernelFn pick_ct_wp(int CT, int WP) {
     return nullptr;
 }
 
-KernelFn pick_kernel(int ks, int stride, int CT, int WP) {
+KernelFn pick_kernel(int ks, int stride, int CT, int WP, int version) {
+    if (version == 2) {
+        if (ks == 1 && stride == 1) return pick_ct_wp2<1, 1>(CT, WP);
+        if (ks == 3 && stride == 1) return pick_ct_wp2<3, 1>(CT, WP);
+        if (ks == 3 && stride == 2) return pick_ct_wp2<3, 2>(CT, WP);
+        return nullptr;
+    }
     if (ks == 1 && stride == 1) return pick_ct_wp<1, 1>(CT, WP);
     if (ks == 3 && stride == 1) return pick_ct_wp<3, 1>(CT, WP);
     if (ks == 3 && stride == 2) return pick_ct_wp<3, 2>(CT, WP);
@@ -224,7 +405,8 @@ constexpr size_t LDS_SOFT = 40 * 1024, LDS_HARD = 64 * 1024;
 
 // Candidate launch plans for one conv: for every wave arrangement (CT, WC) the best output tile, with every
 // feasible staged-channel count.  Sorted by a static cost model; the engine may time the first few (autotune).
-std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, int stride) {
+std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, int stride, bool allow_v2) {
+    static const int use_v2 = env_int("MI355_CONV_V2", 1);
     static const int max_ct = env_int("MI355_MAX_CT", 5);          // tuning knobs (experiments only)
     static const int min_wc = env_int("MI355_MIN_WC", 1);
     std::vector<Plan> out;
@@ -251,9 +433,22 @@ std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, i
                     const int stages = (cin16 + ck - 1) / ck;
                     double cost = infl * (1.0 + 0.03 * halo * nblk) * (1.0 + 0.04 * (stages - 1)) * (1.0 + 0.04 * (CT - 1))
                                   + (lds > LDS_SOFT ? 0.15 : 0.0);
-                    if (cost < best.cost) best = Plan{CT, WP, TW, TH, ck, lds, cost};
+                    if (cost < best.cost) best = Plan{CT, WP, TW, TH, ck, lds, cost, 1, 0};
                 }
-                if (best.cost < 1e30) out.push_back(best);
+                if (best.cost < 1e30) {
+                    out.push_back(best);
+                    // v2 variant of the same tile: dense double-buffered LDS image filled by a DMA loader wave
+                    const int stages = (cin16 + ck - 1) / ck;
+                    const int THin = (best.TH - 1) * stride + ks, TWin = (best.TW - 1) * stride + ks;
+                    const int buf_floats = round_up(THin * TWin * ck, 256);
+                    const size_t lds2 = (size_t)buf_floats * 4 * (stages > 1 ? 2 : 1);
+                    if (allow_v2 && use_v2 && lds2 <= LDS_HARD) {
+                        Plan v2 = best;
+                        v2.version = 2; v2.buf_floats = buf_floats; v2.lds = lds2;
+                        v2.cost = best.cost * (stages > 1 ? 0.97 : 1.02) + (lds2 > LDS_SOFT + 12 * 1024 ? 0.1 : 0.0);
+                        out.push_back(v2);
+                    }
+                }
             }
         }
     std::sort(out.begin(), out.end(), [](const Plan& a, const Plan& b) { return a.cost < b.cost; });
@@ -283,8 +478,9 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     } else {
         a.Hin = c.Hin; a.Win = c.Win; a.Hout = c.Hout; a.Wout = c.Wout;
     }
-    KernelFn fn = pick_kernel(c.k, c.stride, p.CT, p.WP);
+    KernelFn fn = pick_kernel(c.k, c.stride, p.CT, p.WP, p.version);
     if (!fn) return "conv: no kernel instance";
+    a.zeros = c.zeros; a.lds_buf_floats = p.buf_floats;
     a.TW = p.TW; a.TH = p.TH;
     a.tiles_x = (a.Wout + p.TW - 1) / p.TW; a.tiles_y = (a.Hout + p.TH - 1) / p.TH;
     a.TWin = (p.TW - 1) * c.stride + c.k;
@@ -299,7 +495,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     out->grid_y = (unsigned)((a.n_ctiles + p.CT * WC - 1) / (p.CT * WC));
     out->lds = p.lds;
     out->a = a;
-    out->CT = p.CT; out->WP = p.WP;
+    out->CT = p.CT; out->WP = p.WP; out->version = p.version; out->threads = p.version == 2 ? 320 : 256;
     out->flops = 2.0 * c.B * c.Hout * c.Wout * (double)c.Cout * c.Cin * c.k * c.k;
     return nullptr;
 }
@@ -308,7 +504,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
 const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out) {
     if (const char* e = check_args(c)) return e;
     const int H = c.k == 1 ? 1 : c.Hout, W = c.k == 1 ? c.B * c.Hout * c.Wout : c.Wout;
-    const std::vector<Plan> plans = enumerate_plans(H, W, (c.Cout + 15) / 16, c.Cin, c.k, c.stride);
+    const std::vector<Plan> plans = enumerate_plans(H, W, (c.Cout + 15) / 16, c.Cin, c.k, c.stride, c.zeros != nullptr);
     if (plans.empty()) return "conv: no launch plan fits in LDS";
     for (const Plan& p : plans) {
         ConvLaunch l{};
@@ -326,7 +522,7 @@ const char* plan_conv(const ConvArgs& c, ConvLaunch* out) {
 }
 
 const char* run_conv(const ConvLaunch& l, hipStream_t st) {
-    hipLaunchKernelGGL((KernelFn)l.fn, dim3(l.grid_x, l.grid_y), dim3(256), l.lds, st, l.a);
+    hipLaunchKernelGGL((KernelFn)l.fn, dim3(l.grid_x, l.grid_y), dim3(l.threads), l.lds, st, l.a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

@@ -112,8 +112,9 @@ struct mi355_yolo {
     std::vector<FileLevel> levels;
     std::vector<DevConv> dconv;
     float* lut = nullptr;
+    float* zeros = nullptr;             // 256 zero bytes: DMA source of padded LDS slots
     int chunk = 64;
-    int autotune = 12;                  // candidate launch plans timed per conv when a shape is first seen (0 = off)
+    int autotune = 16;                  // candidate launch plans timed per conv when a shape is first seen (0 = off)
     long long n_params = 0, macs640 = 0;
 
     // per-shape state
@@ -156,6 +157,7 @@ mi355_yolo::~mi355_yolo() {
     free_shape();
     for (auto& c : dconv) { if (c.wpk) (void)hipFree(c.wpk); if (c.bias) (void)hipFree(c.bias); if (c.w_raw) (void)hipFree(c.w_raw); }
     if (lut) (void)hipFree(lut);
+    if (zeros) (void)hipFree(zeros);
     if (d_in) (void)hipFree(d_in);
     if (d_rows) (void)hipFree(d_rows); if (d_counts) (void)hipFree(d_counts);
     if (h_rows) (void)hipHostFree(h_rows); if (h_counts) (void)hipHostFree(h_counts);
@@ -231,6 +233,8 @@ static int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
     for (int i = 0; i < 256; ++i) lut[i] = (float)i / 255.0f;     // im /= 255 (IEEE fp32 division)
     HIPCHK(hipMalloc(&h->lut, sizeof(lut)));
     HIPCHK(hipMemcpy(h->lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&h->zeros, 256));
+    HIPCHK(hipMemset(h->zeros, 0, 256));
     return MI355_OK;
 }
 
@@ -248,6 +252,7 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
         h->dbuf_cs[i] = cs;
     }
     h->plans.assign(h->ops.size(), ConvLaunch{});
+    const bool tune_log = getenv("MI355_TUNE_LOG") != nullptr;
     for (size_t i = 0; i < h->ops.size(); ++i) {
         const FileOp& o = h->ops[i];
         if (o.type != OP_CONV) continue;
@@ -257,7 +262,7 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
         a.src = h->dbuf[o.src_buf] + o.src_choff; a.src_cs = h->dbuf_cs[o.src_buf];
         a.dst = h->dbuf[o.dst_buf] + o.dst_choff; a.dst_cs = h->dbuf_cs[o.dst_buf];
         if (o.res_buf >= 0) { a.res = h->dbuf[o.res_buf] + o.res_choff; a.res_cs = h->dbuf_cs[o.res_buf]; }
-        a.wpk = h->dconv[o.conv].wpk; a.bias = h->dconv[o.conv].bias;
+        a.wpk = h->dconv[o.conv].wpk; a.bias = h->dconv[o.conv].bias; a.zeros = h->zeros;
         a.B = nb; a.Hin = Hl / sd_in; a.Win = Wl / sd_in; a.Hout = Hl / sd_out; a.Wout = Wl / sd_out;
         a.Cin = c.cin; a.Cout = c.cout; a.k = c.k; a.stride = c.s; a.pad = c.pad; a.act = c.act;
         if (a.Hout * (int)c.s != a.Hin || a.Wout * (int)c.s != a.Win) return fail(MI355_EFORMAT, "conv resolution mismatch in program");
@@ -281,7 +286,14 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                     if (rep > 0) ms = std::min(ms, t);          // first run warms the instruction cache
                 }
                 if (ms < best_ms) { best_ms = ms; h->plans[i] = cands[k]; }
+                if (tune_log)
+                    fprintf(stderr, "[tune] %-22s %4u->%-4u k%u s%u @%dx%d  v%d CT%d WP%d tile %dx%d ck%d lds %zu grid %ux%u : %.1f us  %.1f TFLOP/s\n",
+                            c.name, c.cin, c.cout, c.k, c.s, a.Hout, a.Wout, cands[k].version, cands[k].CT, cands[k].WP, cands[k].a.TW,
+                            cands[k].a.TH, cands[k].a.ck, cands[k].lds, cands[k].grid_x, cands[k].grid_y, ms * 1e3,
+                            cands[k].flops / (ms * 1e-3) / 1e12);
             }
+            if (tune_log) fprintf(stderr, "[tune] -> v%d CT%d WP%d tile %dx%d ck%d : %.1f us\n", h->plans[i].version, h->plans[i].CT,
+                                  h->plans[i].WP, h->plans[i].a.TW, h->plans[i].a.TH, h->plans[i].a.ck, best_ms * 1e3);
         }
     }
     int A = 0;
@@ -685,7 +697,7 @@ int mi355_op_letterbox(int device_id, const uint8_t* bgr, int n, int height, int
 }
 
 int mi355_op_conv2d(int device_id, const float* x, int n, int h, int w, int cin, const float* w_oihw, const float* bias,
-                    int cout, int k, int stride, int silu, const float* residual, float* y) {
+                    int cout, int k, int stride, int silu, const float* residual, float* y, int plan_index, int* n_plans) {
     if (!x || !w_oihw || !bias || !y || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return fail(MI355_EINVAL, "bad argument");
     if (!((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)))) return fail(MI355_EINVAL, "k/stride not supported");
     if ((h % stride) || (w % stride)) return fail(MI355_EINVAL, "h and w must be multiples of the stride");
@@ -695,7 +707,8 @@ int mi355_op_conv2d(int device_id, const float* x, int n, int h, int w, int cin,
     const size_t npi = (size_t)n * h * w, npo = (size_t)n * ho * wo;
     std::vector<float> xin(npi * cs_in, 0.f), yout(npo * cs_out, 0.f), rs;
     for (size_t p = 0; p < npi; ++p) std::memcpy(&xin[p * cs_in], x + p * cin, (size_t)cin * 4);
-    DevMem dm; float *d_x, *d_y, *d_r = nullptr, *d_w, *d_b;
+    DevMem dm; float *d_x, *d_y, *d_r = nullptr, *d_w, *d_b, *d_z;
+    HIPCHK(dm.alloc(&d_z, 256)); HIPCHK(hipMemset(d_z, 0, 256));
     HIPCHK(dm.alloc(&d_x, xin.size() * 4)); HIPCHK(dm.alloc(&d_y, yout.size() * 4));
     HIPCHK(hipMemcpy(d_x, xin.data(), xin.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(d_y, 0, yout.size() * 4));
@@ -714,8 +727,12 @@ int mi355_op_conv2d(int device_id, const float* x, int n, int h, int w, int cin,
     ConvArgs a{};
     a.src = d_x; a.src_cs = cs_in; a.dst = d_y; a.dst_cs = cs_out; a.res = d_r; a.res_cs = cs_out; a.wpk = d_w; a.bias = d_b;
     a.B = n; a.Hin = h; a.Win = w; a.Hout = ho; a.Wout = wo; a.Cin = cin; a.Cout = cout; a.k = k; a.stride = stride; a.pad = k / 2; a.act = silu ? 1 : 0;
-    ConvLaunch l{};
-    KCHK(plan_conv(a, &l));
+    a.zeros = d_z;
+    std::vector<ConvLaunch> cands;
+    KCHK(plan_conv_candidates(a, &cands));
+    // plan_index: which candidate launch plan to run (tests sweep it to cover v1 and v2 kernels and all wave shapes)
+    const ConvLaunch& l = cands[(size_t)(plan_index < 0 ? 0 : plan_index) % cands.size()];
+    if (n_plans) *n_plans = (int)cands.size();
     KCHK(run_conv(l, nullptr));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(yout.data(), d_y, yout.size() * 4, hipMemcpyDeviceToHost));

@@ -18,22 +18,25 @@ def _f32(a):
 
 
 def conv2d(x_nhwc: np.ndarray, w_oihw: np.ndarray, bias: np.ndarray, stride: int = 1, silu: bool = True,
-           residual: Optional[np.ndarray] = None, device: int = 0) -> np.ndarray:
-    """Fused conv + bias (+SiLU) (+residual): x [N,H,W,Cin] fp32 -> [N,H/s,W/s,Cout]."""
+           residual: Optional[np.ndarray] = None, device: int = 0, plan: int = 0, return_n_plans: bool = False):
+    """Fused conv + bias (+SiLU) (+residual): x [N,H,W,Cin] fp32 -> [N,H/s,W/s,Cout].
+    ``plan`` picks one of the engine's candidate launch plans (all must give identical bits)."""
     x, w, b = _f32(x_nhwc), _f32(w_oihw), _f32(bias)
     n, h, wd, cin = x.shape
     cout, cin2, k, k2 = w.shape
     if cin2 != cin or k != k2 or b.shape != (cout,):
         raise ValueError("shape mismatch between x, w and bias")
     y = np.empty((n, h // stride, wd // stride, cout), dtype=np.float32)
+    npl = C.c_int(0)
     r = None
     if residual is not None:
         r = _f32(residual)
         if r.shape != y.shape:
             raise ValueError("residual must have the output's shape")
     _lib.check(_lib.lib().mi355_op_conv2d(device, x.ctypes.data, n, h, wd, cin, w.ctypes.data, b.ctypes.data, cout, k,
-                                          stride, int(silu), r.ctypes.data if r is not None else None, y.ctypes.data))
-    return y
+                                          stride, int(silu), r.ctypes.data if r is not None else None, y.ctypes.data,
+                                          int(plan), C.byref(npl)))
+    return (y, npl.value) if return_n_plans else y
 
 
 def stem(bgr_u8: np.ndarray, w_oihw: np.ndarray, bias: np.ndarray, stride: int = 2, device: int = 0) -> np.ndarray:

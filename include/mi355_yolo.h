@@ -130,9 +130,12 @@ int  mi355_yolo_last_timing(const mi355_yolo* h, mi355_timing* t);
 
 /* Fused conv + bias (+SiLU) (+residual), NHWC fp32 -- ultralytics/nn/modules/conv.py:Conv.forward_fuse.
  * x[n][h][w][cin] dense, w_oihw[cout][cin][k][k], bias[cout], residual (or NULL) and y dense [n][ho][wo][cout];
- * k in {1,3}, stride in {1,2}, pad = k/2. */
+ * k in {1,3}, stride in {1,2}, pad = k/2.  plan_index selects one of the engine's candidate launch plans (tile shape,
+ * wave arrangement, v1 / v2 staging; 0 = the default guess, taken modulo the number of candidates, which is returned
+ * through n_plans when non-NULL): every plan must give the same bits. */
 int  mi355_op_conv2d(int device_id, const float* x, int n, int h, int w, int cin, const float* w_oihw,
-                     const float* bias, int cout, int k, int stride, int silu, const float* residual, float* y);
+                     const float* bias, int cout, int k, int stride, int silu, const float* residual, float* y,
+                     int plan_index, int* n_plans);
 /* The u8 stem: letterboxed BGR frames -> (x/255, RGB) -> conv k x k stride s (pad k/2, or 2 for k=6) + bias + SiLU. */
 int  mi355_op_stem(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias,
                    int cout, int k, int stride, float* y);

@@ -67,6 +67,29 @@ def test_conv2d_bit_exact_vs_canonical_order_oracle(n, h, w, cin, cout, k, strid
     np.testing.assert_array_equal(y, ref)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,k,stride", [
+    (2, 24, 40, 64, 64, 3, 1), (1, 40, 40, 80, 80, 3, 1), (2, 16, 16, 128, 256, 3, 2), (3, 20, 20, 384, 128, 1, 1),
+    (1, 32, 48, 32, 16, 3, 1), (2, 20, 20, 51, 51, 3, 1), (1, 64, 64, 16, 32, 3, 2), (2, 12, 12, 192, 96, 1, 1),
+])
+def test_every_launch_plan_gives_the_same_bits(n, h, w, cin, cout, k, stride):
+    """All candidate plans (tile shapes, wave arrangements, v1 register-staged / v2 DMA-loader kernels, staged
+    channel counts) must reproduce the canonical-order oracle bit for bit: the autotuner may pick any of them."""
+    from cvsd_amd import ops
+    from oracle import det
+    rng = np.random.default_rng(cin + cout + k + h)
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wt = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((n, h // stride, w // stride, cout), dtype=np.float32)
+    ref = det.conv2d(x, wt, b, stride=stride, act=True, residual=res)
+    y, n_plans = ops.conv2d(x, wt, b, stride=stride, silu=True, residual=res, plan=0, return_n_plans=True)
+    np.testing.assert_array_equal(y, ref)
+    assert n_plans >= 4
+    for plan in range(1, n_plans):
+        np.testing.assert_array_equal(ops.conv2d(x, wt, b, stride=stride, silu=True, residual=res, plan=plan), ref,
+                                      err_msg=f"plan {plan} of {n_plans}")
+
+
 def test_conv2d_asymmetric_identity():
     """A = I check with an asymmetric operand (catches a transposed MFMA fragment map)."""
     from cvsd_amd import ops
