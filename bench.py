@@ -32,8 +32,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="yolov8n")
-    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
-    ap.add_argument("--chunk", type=int, default=0, help="engine batch_chunk (0 = engine default)")
+    ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step")
+    ap.add_argument("--chunk", type=int, default=128, help="engine batch_chunk: frames per pass through the net")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
@@ -131,6 +131,13 @@ def main() -> None:
     conv_flops_frame = 2.0 * sum(c.cout * c.cin * c.k * c.k * (640 // c.stride_div) ** 2 for c in pg.convs if c.cin != 3) * scale
     achieved = conv_flops_frame * B * PROF_STEPS / (conv_ms * 1e-3) / 1e12
     fps = world * B * args.steps / dt
+    # HBM traffic of the conv launches from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
+    # process); only quoted when it was collected on this exact workload
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+    if os.path.exists(tpath) and args.model == "yolov8n" and args.size == 640 and B == 128 and args.chunk == 128:
+        with open(tpath) as f:
+            traffic = json.load(f)["hbm_bytes_per_launch_avg"]
     line = {
         "metric": "frames/s @640x640", "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -141,7 +148,7 @@ def main() -> None:
                    "parallelism": f"frame-sharded dp{world}"},
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (all instances)", "achieved": round(achieved, 2),
                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4),
-                     "traffic": None, "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
+                     "traffic": traffic, "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
                      "launches_per_step": launches // PROF_STEPS,
                      "flop_per_launch_avg": conv_flops_frame * B * PROF_STEPS / max(launches, 1)},
         "device_ms_per_step": {k: round(v, 3) for k, v in kinds.items()},

@@ -45,3 +45,20 @@ for j, name in enumerate(seq):
     else:
         print(f"{name:26s} {'':24s} {'':30s} {r['Grid_Size_X'] + 'x' + r['Grid_Size_Y']:>12s} {r['LDS_Block_Size']:>6s} {int(r['VGPR_Count'])+int(r['Accum_VGPR_Count']):>5d} {us:8.1f}")
 print(f"sum of medians: {tot:.1f} us per pass of {chunk} frames -> {chunk / tot * 1e6:.0f} frames/s device-only")
+# --stats style summary over the matched passes only (the raw rocprofv3 kernel_stats.csv also counts the engine's
+# one-off autotune launches, which are not part of a step)
+import collections
+agg = collections.defaultdict(lambda: [0, 0.0])
+for p in passes:
+    for r in p:
+        kn = r["Kernel_Name"]; kn = kn[:kn.find("(")] if "(" in kn else kn
+        agg[kn][0] += 1; agg[kn][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+conv_calls = sum(v[0] for k, v in agg.items() if "conv_igemm" in k); conv_us = sum(v[1] for k, v in agg.items() if "conv_igemm" in k)
+all_us = sum(v[1] for v in agg.values())
+print(f"\nkernel summary over {len(passes)} real passes:")
+print(f"{'kernel':60s} {'calls':>6s} {'total_us':>11s} {'avg_us':>9s} {'%':>6s}")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print(f"{k[:60]:60s} {v[0]:6d} {v[1]:11.1f} {v[1] / v[0]:9.1f} {100 * v[1] / all_us:6.2f}")
+conv_flops = sum(2.0 * c.cout * c.cin * c.k * c.k * (size // c.stride_div) ** 2 * chunk for c in prog.convs if c.cin != 3)
+print(f"conv_igemm (all instances): {conv_calls} launches, avg {conv_us / conv_calls:.1f} us, {conv_us / len(passes):.1f} us per pass "
+      f"-> {conv_flops / (conv_us / len(passes)) / 1e6:.2f} TFLOP/s")
