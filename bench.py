@@ -49,10 +49,18 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the hot path)")
+    # BENCH_DRYRUN_ONE_GPU=1 (tests only): all ranks share cuda:0 and the collectives run over gloo, to rehearse the
+    # N > 1 code path on a one-GPU box.  The real launch is one rank per GPU over RCCL (backend "nccl").
+    dry = os.environ.get("BENCH_DRYRUN_ONE_GPU") == "1"
+    if dry:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from cvsd_amd import YOLO
     from cvsd_amd import dist as cdist
@@ -100,7 +108,7 @@ def main() -> None:
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dry else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -175,10 +175,13 @@ class YOLO:
             if self.task == "pose":
                 nk = self.kpt_shape[0] * self.kpt_shape[1]
                 kp = torch.from_numpy(r[:, 7:7 + nk].reshape(len(r), *self.kpt_shape).copy())
-            out.append(Results(originals[i] if originals is not None else None, f"image{i}.jpg", self.names,
-                               boxes=torch.from_numpy(data), keypoints=kp, orig_shape=shape,
-                               speed={"preprocess": 0.0, "inference": per_img_ms, "postprocess": 0.0},
-                               anchor_idx=ints[:, 1].copy()))
+            res = Results(originals[i] if originals is not None else None, f"image{i}.jpg", self.names,
+                          boxes=torch.from_numpy(data), keypoints=kp.clone() if kp is not None else None, orig_shape=shape,
+                          speed={"preprocess": 0.0, "inference": per_img_ms, "postprocess": 0.0},
+                          anchor_idx=ints[:, 1].copy())
+            if kp is not None:
+                res.keypoints_raw = kp.numpy()          # before Keypoints() zeroes x,y of joints with conf < 0.5
+            out.append(res)
         return out
 
     __call__ = predict

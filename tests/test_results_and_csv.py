@@ -115,3 +115,28 @@ def test_tracker_assigns_stable_ids():
         for r in out:
             assert ids[tuple(np.round((r[:2] - 3 * step) / 50))] == r[4]
     assert tr.update(np.zeros((0, 6), np.float32)).shape == (0, 8)
+
+
+def test_poselift_bridge_layout(tmp_path):
+    """{frame_num: {person_id: [bbox, kpts(17,3)]}} exactly as shopformer/data/poselift_dataset.py:256-295 parses it"""
+    import pickle
+    from cvsd_amd.poselift_bridge import PoseLiftWriter
+    w = PoseLiftWriter()
+    rows = np.array([[10, 20, 50, 100, 3, 0.9, 0, 0], [200, 40, 260, 160, 7, 0.8, 0, 1]], np.float32)
+    kp = np.random.default_rng(0).random((2, 17, 3)).astype(np.float32)
+    for f in range(12):
+        w.add_frame(f, rows, kp + f)
+    w.add_frame(12, np.zeros((0, 8), np.float32), np.zeros((0, 17, 3), np.float32))
+    p = tmp_path / "Shoplifting003.pkl"
+    w.save(str(p))
+    data = pickle.load(open(p, "rb"))
+    assert sorted(data) == list(range(13)) and sorted(data[0]) == [3, 7] and data[12] == {}
+    bbox, k = data[5][7]
+    assert bbox.tolist() == [200.0, 40.0, 60.0, 120.0] and k.shape == (17, 3)
+    # the reference loader's own acceptance rules (poselift_dataset.py:266-295)
+    for frame_num, frame_data in data.items():
+        for pid, person in frame_data.items():
+            assert isinstance(person, (list, tuple)) and len(person) >= 2
+            assert not np.isnan(np.array(person[1])).any()
+    per_person = {pid: sorted(f for f, d in data.items() if pid in d) for pid in (3, 7)}
+    assert all(len(v) >= 12 for v in per_person.values())          # seq_len 12 windows exist
