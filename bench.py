@@ -191,10 +191,16 @@ def cpu_baseline(args, sd, frames_np, model):
     for g, w in zip(got, want):
         if np.array_equal(g.anchor_idx, w["anchor_idx"].numpy()) and len(g.anchor_idx):
             err = max(err, float(np.abs(g.boxes.data.numpy()[:, :4] - w["boxes"].numpy()[:, :4]).max()))
+    # the canonical-operation-order C oracle on 2 of the frames: the GPU rows must be identical bit for bit
+    from oracle import det
+    dwant, _ = det.predict(det.DetOracleModel(args.model, sd), sample[:2], imgsz=args.size)
+    bit_exact = all(np.array_equal(g.anchor_idx, w["anchor_idx"].numpy()) and
+                    np.array_equal(g.boxes.data.numpy(), w["boxes"].numpy()) for g, w in zip(got[:2], dwant))
     return {"value": round(n * reps / dt, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} of the benchmark frames x {reps} passes through oracle/yolo_oracle.py (torch {torch.__version__} "
                       f"CPU fp32, batch {n})",
-            "parity_vs_gpu": {"frames_with_identical_indices": same, "frames": n, "max_box_abs_err_px": err}}
+            "parity_vs_gpu": {"frames_with_identical_indices": same, "frames": n, "max_box_abs_err_px": err,
+                              "rows_bit_exact_vs_canonical_order_oracle": bool(bit_exact)}}
 
 
 if __name__ == "__main__":

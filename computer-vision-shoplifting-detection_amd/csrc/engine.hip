@@ -124,7 +124,10 @@ struct mi355_yolo {
     std::vector<ConvLaunch> plans;      // per op (valid for OP_CONV)
     float* pred = nullptr; float2* best = nullptr; unsigned long long* keys = nullptr;
     int A = 0, Apow2 = 0;
-    uint8_t* lbox = nullptr;            // letterboxed frames of one chunk
+    uint8_t* lbox = nullptr;            // letterboxed frames of one chunk (also the stable stem input of the graph path)
+    std::vector<std::pair<int, hipGraphExec_t>> graphs;   // (frames in chunk, captured stem..decode sequence)
+    int use_graph = 0;                  // MI355_GRAPH=1: replay stem..decode as a hipGraph (measured: no gain, the small-batch
+                                        // regime is bound by per-kernel latency of tiny grids, not by host launches)
     // per-call scratch (grown on demand)
     uint8_t* d_in = nullptr; size_t d_in_bytes = 0;
     mi355_det* d_rows = nullptr; int* d_counts = nullptr; size_t rows_cap = 0; int counts_cap = 0;
@@ -144,6 +147,8 @@ struct mi355_yolo {
 };
 
 void mi355_yolo::free_shape() {
+    for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+    graphs.clear();
     for (float* p : dbuf) if (p) (void)hipFree(p);
     dbuf.clear(); dbuf_cs.clear(); plans.clear();
     if (pred) (void)hipFree(pred); if (best) (void)hipFree(best); if (keys) (void)hipFree(keys);
@@ -324,9 +329,18 @@ struct Prof {
     }
 };
 
-// run the net (+decode) on nb frames that sit in `frames_dev` (original size h0 x w0, dense)
+static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, const Geometry& g, bool full_pred);
+
+// run the net (+decode) on nb frames that sit in `frames_dev` (original size h0 x w0, dense).
+// Launch-bound regime: the stem..decode sequence (60-100 launches) is captured once per chunk size into a hipGraph
+// and replayed; the frames are first copied into the engine's own staging buffer so the captured pointers stay valid.
 static int run_chunk(mi355_yolo* h, Prof& pf, const uint8_t* frames_dev, int nb, const Geometry& g, bool full_pred) {
     const uint8_t* stem_in = frames_dev;
+    const bool graph = h->use_graph && !h->profiling && !full_pred;
+    if (g.identity && graph) {
+        HIPCHK(hipMemcpyAsync(h->lbox, frames_dev, (size_t)nb * g.Hl * g.Wl * 3, hipMemcpyDeviceToDevice, h->stream));
+        stem_in = h->lbox;
+    }
     if (!g.identity) {
         LetterboxArgs la{};
         la.src = frames_dev; la.H = g.h0; la.W = g.w0; la.frame_stride = (long long)g.h0 * g.w0 * 3; la.row_stride = g.w0 * 3;
@@ -337,6 +351,26 @@ static int run_chunk(mi355_yolo* h, Prof& pf, const uint8_t* frames_dev, int nb,
         pf.end();
         stem_in = h->lbox;
     }
+    if (!graph) return launch_net(h, pf, stem_in, nb, g, full_pred);
+    hipGraphExec_t exec = nullptr;
+    for (auto& ge : h->graphs) if (ge.first == nb) exec = ge.second;
+    if (!exec) {
+        hipGraph_t gr = nullptr;
+        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = launch_net(h, pf, stem_in, nb, g, full_pred);
+        const hipError_t e = hipStreamEndCapture(h->stream, &gr);
+        if (rc) { if (gr) (void)hipGraphDestroy(gr); return rc; }
+        if (e != hipSuccess) return fail(MI355_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        const hipError_t ei = hipGraphInstantiate(&exec, gr, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(gr);
+        if (ei != hipSuccess) return fail(MI355_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+        h->graphs.push_back({nb, exec});
+    }
+    HIPCHK(hipGraphLaunch(exec, h->stream));
+    return MI355_OK;
+}
+
+static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, const Geometry& g, bool full_pred) {
     for (size_t i = 0; i < h->ops.size(); ++i) {
         const FileOp& o = h->ops[i];
         const int sd_out = h->bufs[o.dst_buf].stride_div;
@@ -545,6 +579,7 @@ static int create_impl(const uint8_t* blob, size_t nbytes, int device_id, const 
     h->device = device_id;
     if (opts && opts->struct_size >= (int)sizeof(mi355_opts) && opts->batch_chunk > 0) h->chunk = opts->batch_chunk;
     if (const char* e = getenv("MI355_AUTOTUNE")) h->autotune = std::max(0, atoi(e));
+    if (const char* e = getenv("MI355_GRAPH")) h->use_graph = atoi(e);
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
     const int rc = parse_blob(h.get(), blob, nbytes);
