@@ -32,8 +32,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="yolov8n")
-    ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step")
-    ap.add_argument("--chunk", type=int, default=128, help="engine batch_chunk: frames per pass through the net")
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--chunk", type=int, default=256, help="engine batch_chunk: frames per pass through the net")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
@@ -143,7 +143,7 @@ def main() -> None:
     # process); only quoted when it was collected on this exact workload
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
-    if os.path.exists(tpath) and args.model == "yolov8n" and args.size == 640 and B == 128 and args.chunk == 128:
+    if os.path.exists(tpath) and args.model == "yolov8n" and args.size == 640 and B == 256 and args.chunk == 256:
         with open(tpath) as f:
             traffic = json.load(f)["hbm_bytes_per_launch_avg"]
     line = {

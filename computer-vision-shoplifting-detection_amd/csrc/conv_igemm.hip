@@ -84,7 +84,6 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
     const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
     const int ct0 = (blockIdx.y * WC + wc) * CT;
     const int npix = a.TW * a.TH;
-
     int xoff[PT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
@@ -131,57 +130,60 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
         const int cib0 = c0 >> 4;
         // canonical accumulation order of one output: 16-channel block (outer), tap, MFMA step s, k-group g.
         // (block, tap) is flattened into one runtime loop of pipeline steps; all offsets advance as wave-uniform
-        // scalars.  Two static register sets: the fragments of step i+1 are in flight while step i's MFMAs issue.
+        // scalars.  Weight fragments come from L2 with 1-2k cycles of latency under load, so they are prefetched WD
+        // steps ahead through a ring of WD register sets; pixel fragments (LDS, ~100 cycles) one step ahead through two
+        // sets.  Both cursors CLAMP at the last step instead of guarding the loads: every load is unconditional, which
+        // is what lets hipcc keep counted s_waitcnt vmcnt(N) / lgkmcnt(N) instead of draining the queues.
+        constexpr int WD = (CT <= 2) ? 4 : 2;
         const int n_it = nkk * TAPS;
-        int l_kw = 0, l_kh = 0, l_kk = 0;
-        int l_xoff = 0;                                   // (kh*TWin + kw)*ldp + kk*16   (floats, LDS)
-        int l_woff = cib0 * 256;                          // (tap*cib + cib0 + kk)*256    (floats, packed weights)
         const int wstep = a.cib * 256;
-        f32x4 wf0[CT], xf0[PT], wf1[CT], xf1[PT];
-        auto load_frags = [&](f32x4* wf, f32x4* xf) {
+        int w_it = 0, w_kw = 0, w_kh = 0, w_kk = 0, w_off = cib0 * 256;     // weight cursor: (tap*cib + cib0 + kk)*256 floats
+        int x_it = 0, x_kw = 0, x_kh = 0, x_kk = 0, x_off = 0;              // pixel cursor: (kh*TWin + kw)*ldp + kk*16 floats
+        f32x4 wf[WD][CT], xf[2][PT];
+        auto load_w = [&](f32x4* w) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) wf[ct] = *(const f32x4*)(wbase[ct] + l_woff);      // unconditional: keeps vmcnt counted
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt)
-                xf[pt] = *(const f32x4*)__builtin_assume_aligned(lds + xoff[pt] + l_xoff, 16);
-            // advance to the next step: kw, then kh, then the next 16-channel block
-            ++l_kw; l_xoff += a.ldp; l_woff += wstep;
-            if (l_kw == KS) {
-                l_kw = 0; ++l_kh; l_xoff += (a.TWin - KS) * a.ldp;
-                if (l_kh == KS) { l_kh = 0; ++l_kk; l_xoff = l_kk * 16; l_woff = (cib0 + l_kk) * 256; }
+            for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(wbase[ct] + w_off);
+            if (w_it + 1 < n_it) {
+                ++w_it; ++w_kw; w_off += wstep;
+                if (w_kw == KS) {
+                    w_kw = 0; ++w_kh;
+                    if (w_kh == KS) { w_kh = 0; ++w_kk; w_off = (cib0 + w_kk) * 256; }
+                }
             }
         };
-        auto mma = [&](const f32x4* wf, const f32x4* xf) {
+        auto load_x = [&](f32x4* x) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) x[pt] = *(const f32x4*)__builtin_assume_aligned(lds + xoff[pt] + x_off, 16);
+            if (x_it + 1 < n_it) {
+                ++x_it; ++x_kw; x_off += a.ldp;
+                if (x_kw == KS) {
+                    x_kw = 0; ++x_kh; x_off += (a.TWin - KS) * a.ldp;
+                    if (x_kh == KS) { x_kh = 0; ++x_kk; x_off = x_kk * 16; }
+                }
+            }
+        };
+        auto mma = [&](const f32x4* w, const f32x4* x) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt)
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][s], xf[pt][s], acc[ct][pt], 0, 0, 0);
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][s], x[pt][s], acc[ct][pt], 0, 0, 0);
         };
-        load_frags(wf0, xf0);
-        int it = 0;
-        for (; it + 2 < n_it; it += 2) {                 // steady state: unconditional prefetches -> counted vmcnt
-            load_frags(wf1, xf1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(wf0, xf0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_frags(wf0, xf0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(wf1, xf1);
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < WD - 1; ++j) load_w(wf[j]);        // steps 0 .. WD-2
+        load_x(xf[0]);                                          // step 0
+        for (int it = 0; it < n_it; it += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                load_w(wf[(j + WD - 1) % WD]);                  // step it+j+WD-1 (clamped)
+                load_x(xf[(j + 1) & 1]);                        // step it+j+1    (clamped)
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + j < n_it) mma(wf[j % WD], xf[j & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (it + 1 < n_it) {                             // two steps left
-            load_frags(wf1, xf1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(wf0, xf0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(wf1, xf1);
-        } else {                                         // one step left
-            mma(wf0, xf0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
     }
 
     conv_epilogue<STRIDE, PT, CT, WP>(a, acc, lane, wp, ct0, b, oy0, ox0, npix);
@@ -203,27 +205,41 @@ __device__ __forceinline__ int lds_swz(int pix, int sshift) {
 
 template <int KS, int STRIDE, int PT, int CT, int WP>
 __global__ __launch_bounds__(320) void conv_igemm_f32_v2(ConvKArgs a) {
+    // PERSISTENT over output tiles: block x handles tiles x, x + gridDim.x, ...  The unit of pipelining is one
+    // (tile, K-stage) item; the loader wave always works one item ahead of the compute waves, so the HBM reads of
+    // tile t+1 (and, through other blocks, the epilogue writes of tile t-1) overlap the MFMAs of tile t.
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int WC = 4 / WP;
     constexpr int TAPS = KS * KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool loader = wave == 4;
     const int wp = wave % WP, wc = (wave & 3) / WP;
-    int t = blockIdx.x;
-    const int tx = t % a.tiles_x; t /= a.tiles_x;
-    const int ty = t % a.tiles_y;
-    const int b = t / a.tiles_y;
-    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
-    const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
     const int ct0 = (blockIdx.y * WC + wc) * CT;
     const int npix = a.TW * a.TH;
     const int sshift = a.ck4_shift, S = a.ck >> 2;
     const int nst = (a.Cin + a.ck - 1) / a.ck;
-    const float* srcb = a.src + (size_t)b * a.Hin * a.Win * a.src_cs;
     const int pieces = ((a.npix_in << sshift) + 63) >> 6;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int n_tiles = a.n_tiles_total;
+    const int my_tiles = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int n_items = my_tiles * nst;
 
-    auto issue_stage = [&](int st, float* buf) {           // loader wave only
-        const int c0 = st * a.ck;
+    auto tile_origin = [&](int item, int& b, int& oy0, int& ox0) {
+        int t = (int)blockIdx.x + (item / nst) * (int)gridDim.x;
+        const int tx = t % a.tiles_x; t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        b = t / a.tiles_y;
+        oy0 = ty * a.TH; ox0 = tx * a.TW;
+    };
+    (void)tiles_per_img;
+
+    auto issue_item = [&](int item) {                        // loader wave only
+        int b, oy0, ox0;
+        tile_origin(item, b, oy0, ox0);
+        const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
+        const int c0 = (item % nst) * a.ck;
+        float* buf = lds + (item & 1) * a.lds_buf_floats;
+        const float* srcb = a.src + (size_t)b * a.Hin * a.Win * a.src_cs;
         for (int j = 0; j < pieces; ++j) {
             const int i = j * 64 + lane;
             const int pix = i >> sshift;
@@ -248,87 +264,192 @@ __global__ __launch_bounds__(320) void conv_igemm_f32_v2(ConvKArgs a) {
         const int lx = p - ly * a.TW;
         pbase[pt] = (ly * STRIDE) * a.TWin + lx * STRIDE;                  // LDS pixel index of tap (0,0)
     }
-    f32x4 acc[CT][PT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int g = lane >> 4;
+    const int g4 = lane >> 4;
     const float* wbase[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
         wbase[ct] = a.wpk + (size_t)ctile * TAPS * a.cib * 256 + lane * 4;
     }
+    f32x4 acc[CT][PT];
 
-    if (loader) issue_stage(0, lds);
+    if (loader && n_items > 0) issue_item(0);
     __syncthreads();
-    for (int st = 0; st < nst; ++st) {
+    for (int item = 0; item < n_items; ++item) {
         if (loader) {
-            if (st + 1 < nst) issue_stage(st + 1, lds + ((st + 1) & 1) * a.lds_buf_floats);
+            if (item + 1 < n_items) issue_item(item + 1);
         } else {
-            const float* buf = lds + (st & 1) * a.lds_buf_floats;
+            const int st = item % nst;
+            if (st == 0) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            const float* buf = lds + (item & 1) * a.lds_buf_floats;
             const int c0 = st * a.ck;
             const int rem = a.Cin - c0;
             const int nkk = ((rem < a.ck ? rem : a.ck) + 15) >> 4;
             const int cib0 = c0 >> 4;
+            constexpr int WD = (CT <= 2) ? 4 : 2;
             const int n_it = nkk * TAPS;
-            int l_kw = 0, l_kh = 0, l_kk = 0;
-            int l_pix = 0;                                    // kh*TWin + kw (LDS pixels)
-            int l_woff = cib0 * 256;
             const int wstep = a.cib * 256;
-            f32x4 wf0[CT], xf0[PT], wf1[CT], xf1[PT];
-            auto load_frags = [&](f32x4* wf, f32x4* xf) {
+            int w_it = 0, w_kw = 0, w_kh = 0, w_kk = 0, w_off = cib0 * 256;
+            int x_it = 0, x_kw = 0, x_kh = 0, x_kk = 0, x_pix = 0;          // pixel cursor: kh*TWin + kw (LDS pixels)
+            f32x4 wf[WD][CT], xf[2][PT];
+            auto load_w = [&](f32x4* w) {
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) wf[ct] = *(const f32x4*)(wbase[ct] + l_woff);
-#pragma unroll
-                for (int pt = 0; pt < PT; ++pt) {
-                    const int pix = pbase[pt] + l_pix;
-                    xf[pt] = *(const f32x4*)__builtin_assume_aligned(
-                        buf + (pix << (sshift + 2)) + ((((l_kk << 2) + g) ^ lds_swz(pix, sshift)) << 2), 16);
-                }
-                ++l_kw; ++l_pix; l_woff += wstep;
-                if (l_kw == KS) {
-                    l_kw = 0; ++l_kh; l_pix += a.TWin - KS;
-                    if (l_kh == KS) { l_kh = 0; ++l_kk; l_pix = 0; l_woff = (cib0 + l_kk) * 256; }
+                for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(wbase[ct] + w_off);
+                if (w_it + 1 < n_it) {
+                    ++w_it; ++w_kw; w_off += wstep;
+                    if (w_kw == KS) {
+                        w_kw = 0; ++w_kh;
+                        if (w_kh == KS) { w_kh = 0; ++w_kk; w_off = (cib0 + w_kk) * 256; }
+                    }
                 }
             };
-            auto mma = [&](const f32x4* wf, const f32x4* xf) {
+            auto load_x = [&](f32x4* x) {
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    const int pix = pbase[pt] + x_pix;
+                    x[pt] = *(const f32x4*)__builtin_assume_aligned(
+                        buf + (pix << (sshift + 2)) + ((((x_kk << 2) + g4) ^ lds_swz(pix, sshift)) << 2), 16);
+                }
+                if (x_it + 1 < n_it) {
+                    ++x_it; ++x_kw; ++x_pix;
+                    if (x_kw == KS) {
+                        x_kw = 0; ++x_kh; x_pix += a.TWin - KS;
+                        if (x_kh == KS) { x_kh = 0; ++x_kk; x_pix = 0; }
+                    }
+                }
+            };
+            auto mma = [&](const f32x4* w, const f32x4* x) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                         for (int pt = 0; pt < PT; ++pt)
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][s], xf[pt][s], acc[ct][pt], 0, 0, 0);
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][s], x[pt][s], acc[ct][pt], 0, 0, 0);
             };
-            load_frags(wf0, xf0);
-            int it = 0;
-            for (; it + 2 < n_it; it += 2) {
-                load_frags(wf1, xf1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(wf0, xf0);
-                __builtin_amdgcn_sched_barrier(0);
-                load_frags(wf0, xf0);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(wf1, xf1);
-                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < WD - 1; ++j) load_w(wf[j]);
+            load_x(xf[0]);
+            for (int it = 0; it < n_it; it += 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    load_w(wf[(j + WD - 1) % WD]);
+                    load_x(xf[(j + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (it + j < n_it) mma(wf[j % WD], xf[j & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            if (it + 1 < n_it) {
-                load_frags(wf1, xf1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(wf0, xf0);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(wf1, xf1);
-            } else {
-                mma(wf0, xf0);
+            if (st == nst - 1) {
+                int b, oy0, ox0;
+                tile_origin(item, b, oy0, ox0);
+                conv_epilogue<STRIDE, PT, CT, WP>(a, acc, lane, wp, ct0, b, oy0, ox0, npix);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
-    if (loader) return;
-    conv_epilogue<STRIDE, PT, CT, WP>(a, acc, lane, wp, ct0, b, oy0, ox0, npix);
+}
+
+// ---------------------------------------------------------------------------------------------- v3 (1x1 only)
+// Pointwise convs have no tap reuse, so staging pixels through LDS buys nothing: here every wave streams its pixel
+// fragments straight from global memory into the MFMA B-operand layout (lane (p, g) reads the 16 bytes of channels
+// 4g..4g+3 of pixel p: 64 contiguous bytes per pixel per 16-channel block), with a 4-deep register prefetch ring for
+// pixels (HBM latency) and weights (L2 latency).  No LDS, no barriers: waves drift apart and overlap each other's
+// epilogues.  Same canonical accumulation order as v1 (16-channel block outer, step s, k-group g).
+template <int PT, int CT>
+__global__ __launch_bounds__(256) void conv1x1_stream_f32(ConvKArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4;
+    const int total = a.Wout;                                        // flattened pixels (Hout == 1)
+    const int tile0 = ((int)blockIdx.x * 4 + wave) * PT;             // first 16-pixel tile of this wave
+    const int ct0 = (int)blockIdx.y * CT;
+    const float* xbase[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        int p = (tile0 + pt) * 16 + (lane & 15);
+        p = p < total ? p : total - 1;                               // clamp: results of padded pixels are never stored
+        xbase[pt] = a.src + (size_t)p * a.src_cs + 4 * g;
+    }
+    const float* wbase[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        wbase[ct] = a.wpk + (size_t)ctile * a.cib * 256 + lane * 4;
+    }
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int D = 4;                                             // prefetch depth (steps in flight: D-1)
+    const int n_it = a.cib;
+    // in the last 16-channel block the lanes whose 4 channels lie beyond round_up(Cin, 4) read zeros instead
+    const bool tail_oob = (n_it - 1) * 16 + 4 * g >= a.cin4;
+    f32x4 wf[D][CT], xf[D][PT];
+    int l_it = 0;
+    auto load = [&](f32x4* w, f32x4* x) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(wbase[ct] + l_it * 256);
+        const bool oob = tail_oob && (l_it == n_it - 1);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const float* px = oob ? a.zeros : xbase[pt] + l_it * 16;
+            x[pt] = *(const f32x4*)px;
+        }
+        if (l_it + 1 < n_it) ++l_it;                                 // clamp instead of guarding the loads
+    };
+    auto mma = [&](const f32x4* w, const f32x4* x) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][s], x[pt][s], acc[ct][pt], 0, 0, 0);
+    };
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) load(wf[j], xf[j]);
+    for (int it = 0; it < n_it; it += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            load(wf[(j + D - 1) % D], xf[(j + D - 1) % D]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + j < n_it) mma(wf[j], xf[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // epilogue (same math as conv_epilogue, flattened pixel index)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int p = (tile0 + pt) * 16 + (lane & 15);
+        const bool ok = p < total;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = (ct0 + ct) * 16 + g * 4;
+            if (!ok || c >= a.Cout) continue;
+            f32x4 v = acc[ct][pt] + *(const f32x4*)(a.bias + c);
+            if (a.act) {
+                v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
+            }
+            float* d = a.dst + (size_t)p * a.dst_cs + c;
+            if (c + 3 < a.Cout) {
+                if (a.res) v += *(const f32x4*)(a.res + (size_t)p * a.res_cs + c);
+                *(f32x4*)d = v;
+            } else {
+                for (int i = 0; i < 4 && c + i < a.Cout; ++i) {
+                    float r = v[i];
+                    if (a.res) r += a.res[(size_t)p * a.res_cs + c + i];
+                    d[i] = r;
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -383,6 +504,16 @@ KernelFn pick_ct_wp(int CT, int WP) {
     return nullptr;
 }
 
+KernelFn pick_stream(int CT, int PT) {
+    if (CT == 1 && PT == 2) return &conv1x1_stream_f32<2, 1>;
+    if (CT == 1 && PT == 4) return &conv1x1_stream_f32<4, 1>;
+    if (CT == 2 && PT == 2) return &conv1x1_stream_f32<2, 2>;
+    if (CT == 2 && PT == 4) return &conv1x1_stream_f32<4, 2>;
+    if (CT == 4 && PT == 2) return &conv1x1_stream_f32<2, 4>;
+    if (CT == 4 && PT == 4) return &conv1x1_stream_f32<4, 4>;
+    return nullptr;
+}
+
 KernelFn pick_kernel(int ks, int stride, int CT, int WP, int version) {
     if (version == 2) {
         if (ks == 1 && stride == 1) return pick_ct_wp2<1, 1>(CT, WP);
@@ -406,7 +537,7 @@ constexpr size_t LDS_SOFT = 40 * 1024, LDS_HARD = 64 * 1024;
 // Candidate launch plans for one conv: for every wave arrangement (CT, WC) the best output tile, with every
 // feasible staged-channel count.  Sorted by a static cost model; the engine may time the first few (autotune).
 std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, int stride, bool allow_v2) {
-    static const int use_v2 = env_int("MI355_CONV_V2", 1);
+    static const int use_v2 = env_int("MI355_CONV_V2", 0);   // the loader-wave kernel never won on this network: opt-in
     static const int max_ct = env_int("MI355_MAX_CT", 5);          // tuning knobs (experiments only)
     static const int min_wc = env_int("MI355_MIN_WC", 1);
     std::vector<Plan> out;
@@ -441,16 +572,29 @@ std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, i
                     const int stages = (cin16 + ck - 1) / ck;
                     const int THin = (best.TH - 1) * stride + ks, TWin = (best.TW - 1) * stride + ks;
                     const int buf_floats = round_up(THin * TWin * ck, 256);
-                    const size_t lds2 = (size_t)buf_floats * 4 * (stages > 1 ? 2 : 1);
+                    const size_t lds2 = (size_t)buf_floats * 4 * 2;      // always double-buffered: the pipeline runs across tiles
                     if (allow_v2 && use_v2 && lds2 <= LDS_HARD) {
                         Plan v2 = best;
                         v2.version = 2; v2.buf_floats = buf_floats; v2.lds = lds2;
-                        v2.cost = best.cost * (stages > 1 ? 0.97 : 1.02) + (lds2 > LDS_SOFT + 12 * 1024 ? 0.1 : 0.0);
+                        v2.cost = best.cost * 0.98 + (lds2 > LDS_SOFT + 24 * 1024 ? 0.1 : 0.0);
                         out.push_back(v2);
                     }
                 }
             }
         }
+    if (ks == 1 && allow_v2) {        // streaming pointwise kernel (needs the zero page as well): CT x PT register tiles
+        static const int use_v3 = env_int("MI355_CONV_V3", 1);
+        const int cts[3] = {1, 2, 4}, pts[2] = {2, 4};
+        for (int ci = 0; ci < 3 && use_v3; ++ci)
+            for (int pi = 0; pi < 2; ++pi) {
+                const int CT = cts[ci], PT = pts[pi];
+                if (CT > n_ctiles && CT != 1) continue;
+                const int nblk = (n_ctiles + CT - 1) / CT;
+                Plan p3{CT, 4, PT * 64, 1, 16, 0, 0.0, 3, PT};
+                p3.cost = (double)nblk * CT / n_ctiles * (1.0 + 0.05 * nblk) * 0.9;
+                out.push_back(p3);
+            }
+    }
     std::sort(out.begin(), out.end(), [](const Plan& a, const Plan& b) { return a.cost < b.cost; });
     return out;
 }
@@ -478,7 +622,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     } else {
         a.Hin = c.Hin; a.Win = c.Win; a.Hout = c.Hout; a.Wout = c.Wout;
     }
-    KernelFn fn = pick_kernel(c.k, c.stride, p.CT, p.WP, p.version);
+    KernelFn fn = p.version == 3 ? pick_stream(p.CT, p.buf_floats) : pick_kernel(c.k, c.stride, p.CT, p.WP, p.version);
     if (!fn) return "conv: no kernel instance";
     a.zeros = c.zeros; a.lds_buf_floats = p.buf_floats;
     a.TW = p.TW; a.TH = p.TH;
@@ -491,11 +635,24 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     a.ck4_shift = (p.ck == 64 ? 4 : p.ck == 32 ? 3 : 2);
     const int WC = 4 / p.WP;
     out->fn = (const void*)fn;
-    out->grid_x = (unsigned)((long)B * a.tiles_x * a.tiles_y);
+    a.n_tiles_total = (int)((long)B * a.tiles_x * a.tiles_y);
+    out->grid_x = (unsigned)a.n_tiles_total;
+    if (p.version == 2) {      // persistent: as many blocks as stay resident (LDS-limited), each loops over tiles
+        const int per_cu = std::max(1, std::min(6, (int)((size_t)(160 * 1024) / std::max<size_t>(p.lds, 1))));
+        const unsigned cap = (unsigned)std::max(1, 256 * per_cu / (int)std::max(1, (a.n_ctiles + p.CT * (4 / p.WP) - 1) / (p.CT * (4 / p.WP))));
+        out->grid_x = std::min(out->grid_x, cap);
+    }
     out->grid_y = (unsigned)((a.n_ctiles + p.CT * WC - 1) / (p.CT * WC));
     out->lds = p.lds;
     out->a = a;
     out->CT = p.CT; out->WP = p.WP; out->version = p.version; out->threads = p.version == 2 ? 320 : 256;
+    if (p.version == 3) {          // streaming 1x1: block = 4 waves x PT pixel tiles, grid.y over cout blocks of CT tiles
+        const int PT = p.buf_floats;
+        out->grid_x = (unsigned)((a.Wout + 4 * PT * 16 - 1) / (4 * PT * 16));
+        out->grid_y = (unsigned)((a.n_ctiles + p.CT - 1) / p.CT);
+        out->lds = 0;
+        out->a.tiles_x = (int)out->grid_x;
+    }
     out->flops = 2.0 * c.B * c.Hout * c.Wout * (double)c.Cout * c.Cin * c.k * c.k;
     return nullptr;
 }

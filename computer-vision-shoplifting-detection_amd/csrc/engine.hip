@@ -388,14 +388,26 @@ static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, c
         } else if (o.type == OP_CONV) {
             ConvLaunch l = h->plans[i];
             if (nb != h->cur_nb) {             // tail chunk: same buffers, fewer frames
+                if (h->convs[o.conv].k == 1 && l.version == 3) {
+                    const int sd_in = h->bufs[o.src_buf].stride_div;
+                    l.a.Win = l.a.Wout = nb * (g.Hl / sd_in) * (g.Wl / sd_in);
+                    const int per_block = 4 * 16 * (int)((size_t)l.a.TW / 64);       // TW = PT * 64 pixels per block
+                    l.grid_x = (unsigned)((l.a.Wout + per_block - 1) / per_block);
+                    if (pf.begin(K_CONV)) return fail(MI355_EHIP, "event");
+                    KCHK(run_conv(l, h->stream));
+                    pf.end();
+                    continue;
+                }
                 if (h->convs[o.conv].k == 1) {
                     const int sd_in = h->bufs[o.src_buf].stride_div;
                     l.a.Win = l.a.Wout = nb * (g.Hl / sd_in) * (g.Wl / sd_in);
                     l.a.tiles_x = (l.a.Wout + l.a.TW - 1) / l.a.TW;
-                    l.grid_x = (unsigned)l.a.tiles_x;
+                    l.a.n_tiles_total = l.a.tiles_x;
                 } else {
-                    l.grid_x = (unsigned)((long)nb * l.a.tiles_x * l.a.tiles_y);
+                    l.a.n_tiles_total = (int)((long)nb * l.a.tiles_x * l.a.tiles_y);
                 }
+                // v1: one block per tile; v2 (persistent): keep the planned grid unless fewer tiles exist
+                l.grid_x = l.version == 2 ? std::min(l.grid_x, (unsigned)l.a.n_tiles_total) : (unsigned)l.a.n_tiles_total;
             }
             if (pf.begin(K_CONV)) return fail(MI355_EHIP, "event");
             KCHK(run_conv(l, h->stream));
@@ -772,6 +784,53 @@ int mi355_op_conv2d(int device_id, const float* x, int n, int h, int w, int cin,
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(yout.data(), d_y, yout.size() * 4, hipMemcpyDeviceToHost));
     for (size_t p = 0; p < npo; ++p) std::memcpy(y + p * cout, &yout[p * cs_out], (size_t)cout * 4);
+    return MI355_OK;
+}
+
+int mi355_bench_conv2d(int device_id, int n, int h, int w, int cin, int cout, int k, int stride, int silu, int residual,
+                       int plan_index, int iters, float* avg_ms, int* n_plans, char* plan_desc, int plan_desc_len) {
+    if (!avg_ms || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || iters <= 0) return fail(MI355_EINVAL, "bad argument");
+    if (!((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)))) return fail(MI355_EINVAL, "k/stride not supported");
+    HIPCHK(hipSetDevice(device_id));
+    const int ho = h / stride, wo = w / stride, cs_in = round_up(cin, 4), cs_out = round_up(cout, 4);
+    const size_t nin = (size_t)n * h * w * cs_in, nout = (size_t)n * ho * wo * cs_out;
+    DevMem dm; float *d_x, *d_y, *d_r = nullptr, *d_w, *d_b, *d_z;
+    HIPCHK(dm.alloc(&d_x, nin * 4)); HIPCHK(dm.alloc(&d_y, nout * 4)); HIPCHK(dm.alloc(&d_z, 256)); HIPCHK(hipMemset(d_z, 0, 256));
+    {   // random activations / weights (benchmarks on zeros read high: DVFS)
+        std::vector<float> hx(std::min<size_t>(nin, 1u << 22));
+        unsigned st = 12345u;
+        for (float& v : hx) { st = st * 1664525u + 1013904223u; v = ((st >> 8) & 0xffff) / 32768.0f - 1.0f; }
+        for (size_t o = 0; o < nin; o += hx.size())
+            HIPCHK(hipMemcpy(d_x + o, hx.data(), std::min(hx.size(), nin - o) * 4, hipMemcpyHostToDevice));
+        if (residual) { HIPCHK(dm.alloc(&d_r, nout * 4)); HIPCHK(hipMemcpy(d_r, d_x, std::min(nin, nout) * 4, hipMemcpyDeviceToDevice)); }
+        std::vector<float> wt((size_t)cout * cin * k * k), pk(packed_weight_floats(cout, cin, k)), bp(round_up(cout, 16), 0.1f);
+        for (float& v : wt) { st = st * 1664525u + 1013904223u; v = (((st >> 8) & 0xffff) / 32768.0f - 1.0f) / std::sqrt((float)cin * k * k); }
+        pack_conv_weights(wt.data(), cout, cin, k, pk.data());
+        HIPCHK(dm.alloc(&d_w, pk.size() * 4)); HIPCHK(dm.alloc(&d_b, bp.size() * 4));
+        HIPCHK(hipMemcpy(d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+    }
+    ConvArgs a{};
+    a.src = d_x; a.src_cs = cs_in; a.dst = d_y; a.dst_cs = cs_out; a.res = d_r; a.res_cs = cs_out; a.wpk = d_w; a.bias = d_b; a.zeros = d_z;
+    a.B = n; a.Hin = h; a.Win = w; a.Hout = ho; a.Wout = wo; a.Cin = cin; a.Cout = cout; a.k = k; a.stride = stride; a.pad = k / 2; a.act = silu ? 1 : 0;
+    std::vector<ConvLaunch> cands;
+    KCHK(plan_conv_candidates(a, &cands));
+    if (n_plans) *n_plans = (int)cands.size();
+    const ConvLaunch& l = cands[(size_t)(plan_index < 0 ? 0 : plan_index) % cands.size()];
+    if (plan_desc && plan_desc_len > 0)
+        snprintf(plan_desc, plan_desc_len, "v%d CT%d WP%d tile %dx%d ck%d lds %zu grid %ux%u", l.version, l.CT, l.WP, l.a.TW, l.a.TH, l.a.ck,
+                 l.lds, l.grid_x, l.grid_y);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) KCHK(run_conv(l, nullptr));
+    HIPCHK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) KCHK(run_conv(l, nullptr));
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_ms = ms / iters;
     return MI355_OK;
 }
 

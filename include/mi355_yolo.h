@@ -136,6 +136,10 @@ int  mi355_yolo_last_timing(const mi355_yolo* h, mi355_timing* t);
 int  mi355_op_conv2d(int device_id, const float* x, int n, int h, int w, int cin, const float* w_oihw,
                      const float* bias, int cout, int k, int stride, int silu, const float* residual, float* y,
                      int plan_index, int* n_plans);
+/* Device-resident timing of one conv launch plan on random data (diagnostics / tuning): average milliseconds over
+ * `iters` back-to-back launches of candidate plan `plan_index`; plan_desc (optional) receives a description. */
+int  mi355_bench_conv2d(int device_id, int n, int h, int w, int cin, int cout, int k, int stride, int silu, int residual,
+                        int plan_index, int iters, float* avg_ms, int* n_plans, char* plan_desc, int plan_desc_len);
 /* The u8 stem: letterboxed BGR frames -> (x/255, RGB) -> conv k x k stride s (pad k/2, or 2 for k=6) + bias + SiLU. */
 int  mi355_op_stem(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias,
                    int cout, int k, int stride, float* y);
