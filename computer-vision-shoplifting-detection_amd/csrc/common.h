@@ -37,6 +37,7 @@ struct ConvKArgs {
     const float* zeros;        // >= 16 bytes of zeros (source of out-of-image / beyond-Cin slots of the v2 LDS-DMA loader)
     int lds_buf_floats;        // v2: floats per LDS stage buffer
     int n_tiles_total;         // B * tiles_x * tiles_y (v2 blocks loop over tiles)
+    unsigned long long* debug; // diagnostics: per-wave phase stamps (6 words per wave), nullptr in product launches
 };
 // A planned launch: kernel instance, grid, LDS bytes and kernel arguments.  Planning (tile / wave-arrangement
 // search) is done once per (op, shape) by the engine; run_conv only enqueues.

@@ -33,10 +33,28 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_f(float v) { return det_silu(v); }
 
-// bias + SiLU (+ residual) and the 16-byte stores: a lane holds 4 consecutive couts of one pixel per tile
+// bias + SiLU (+ residual) and the 16-byte stores: a lane holds 4 consecutive couts of one pixel per tile.
+// Two passes: all the ALU work first (16 independent SiLU chains per lane interleave freely), then the stores back to
+// back.  t_mid (diagnostics) receives the time between the passes.
 template <int STRIDE, int PT, int CT, int WP>
-__device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x4 (&acc)[CT][PT], int lane, int wp, int ct0, int b,
-                                              int oy0, int ox0, int npix) {
+__device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x4 (&acc)[CT][PT], const f32x4 (&bias4)[CT], int lane, int wp,
+                                              int ct0, int b, int oy0, int ox0, int npix, unsigned long long* t_mid = nullptr) {
+    if (a.act) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                f32x4 v = acc[ct][pt] + bias4[ct];
+                v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
+                acc[ct][pt] = v;
+            }
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = acc[ct][pt] + bias4[ct];
+    }
+    if (t_mid) *t_mid = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int p = (wp * PT + pt) * 16 + (lane & 15);
@@ -50,10 +68,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x4 (&acc)[C
         for (int ct = 0; ct < CT; ++ct) {
             const int c = (ct0 + ct) * 16 + (lane >> 4) * 4;
             if (!ok || c >= a.Cout) continue;
-            f32x4 v = acc[ct][pt] + *(const f32x4*)(a.bias + c);
-            if (a.act) {
-                v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
-            }
+            f32x4 v = acc[ct][pt];
             float* d = a.dst + po * a.dst_cs + c;
             if (c + 3 < a.Cout) {
                 if (a.res) v += *(const f32x4*)(a.res + po * a.res_cs + c);
@@ -84,6 +99,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
     const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
     const int ct0 = (blockIdx.y * WC + wc) * CT;
     const int npix = a.TW * a.TH;
+    // diagnostics only (a.debug == nullptr in every product launch): per-wave phase stamps
+    unsigned long long t_start = 0, t_stage = 0, t_loop = 0, acc_stage = 0, acc_loop = 0, acc_ld = 0;
+    unsigned long long r_start = 0;
+    if (a.debug) { t_start = __builtin_amdgcn_s_memtime(); r_start = __builtin_amdgcn_s_memrealtime(); }
     int xoff[PT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
@@ -108,23 +127,48 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
         const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
         wbase[ct] = a.wpk + (size_t)ctile * TAPS * a.cib * 256 + lane * 4;
     }
+    // the bias of this lane's 4 couts per cout tile is fetched now (the load's L2 latency hides under the staging) and
+    // not in the epilogue, where it would sit on the block's critical path
+    f32x4 bias4[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        bias4[ct] = *(const f32x4*)(a.bias + ctile * 16 + (lane >> 4) * 4);
+    }
     const int ck4m = (a.ck >> 2) - 1;
     const int total_f4 = a.npix_in << a.ck4_shift;
 
     for (int c0 = 0; c0 < a.Cin; c0 += a.ck) {
         if (c0) __syncthreads();
+        if (a.debug) t_stage = __builtin_amdgcn_s_memtime();
         // ---- stage the halo tile, channels [c0, c0+ck), zero-filled outside the image / beyond Cin ----
-        for (int idx = tid; idx < total_f4; idx += 256) {
-            const int pix = idx >> a.ck4_shift, q = idx & ck4m;
-            const int iy = (int)(((float)pix + 0.5f) * a.inv_TWin);
-            const int ix = pix - iy * a.TWin;
-            const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + 4 * q;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && c < a.cin4)
-                v = *(const f32x4*)(srcb + ((size_t)gy * a.Win + gx) * a.src_cs + c);
-            *(f32x4*)(lds + pix * a.ldp + 4 * q) = v;
+        // Loads are issued in batches of 8 per thread BEFORE any of them is consumed (out-of-image / beyond-Cin slots
+        // read a zero page instead of branching), so one HBM/L2 latency is paid per batch, not per float4.
+        for (int base = 0; base < total_f4; base += 8 * 256) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int pix = idx >> a.ck4_shift, q = idx & ck4m;
+                const int iy = (int)(((float)pix + 0.5f) * a.inv_TWin);
+                const int ix = pix - iy * a.TWin;
+                const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + 4 * q;
+                const bool inb = idx < total_f4 && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && c < a.cin4;
+                const float* g = inb ? srcb + ((size_t)gy * a.Win + gx) * a.src_cs + c : a.zeros;
+                v[u] = *(const f32x4*)g;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                if (idx < total_f4) {
+                    const int pix = idx >> a.ck4_shift, q = idx & ck4m;
+                    *(f32x4*)(lds + pix * a.ldp + 4 * q) = v[u];
+                }
+            }
         }
+        if (a.debug) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); acc_ld += __builtin_amdgcn_s_memtime() - t_stage; }
         __syncthreads();
+        if (a.debug) { t_loop = __builtin_amdgcn_s_memtime(); acc_stage += t_loop - t_stage; }
         const int rem = a.Cin - c0;
         const int nkk = ((rem < a.ck ? rem : a.ck) + 15) >> 4;
         const int cib0 = c0 >> 4;
@@ -184,9 +228,25 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (a.debug) acc_loop += __builtin_amdgcn_s_memtime() - t_loop;
     }
 
-    conv_epilogue<STRIDE, PT, CT, WP>(a, acc, lane, wp, ct0, b, oy0, ox0, npix);
+    unsigned long long t_epi = 0;
+    if (a.debug) t_epi = __builtin_amdgcn_s_memtime();
+    unsigned long long t_mid = 0;
+    conv_epilogue<STRIDE, PT, CT, WP>(a, acc, bias4, lane, wp, ct0, b, oy0, ox0, npix, a.debug ? &t_mid : nullptr);
+    if (a.debug) {
+        const unsigned long long t_alu = t_mid;                               // end of the ALU pass
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        acc_ld = (acc_ld << 24) | ((t_alu - t_epi) & 0xffffff);
+        if (lane == 0) {
+            const size_t w = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+            unsigned long long* o = a.debug + w * 6;
+            o[0] = acc_ld; o[1] = acc_stage; o[2] = acc_loop; o[3] = t_end - t_epi; o[4] = t_end - t_start;
+            o[5] = __builtin_amdgcn_s_memrealtime() - r_start;      // 100 MHz ticks over the same span
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- v2
@@ -272,6 +332,12 @@ __global__ __launch_bounds__(320) void conv_igemm_f32_v2(ConvKArgs a) {
         wbase[ct] = a.wpk + (size_t)ctile * TAPS * a.cib * 256 + lane * 4;
     }
     f32x4 acc[CT][PT];
+    f32x4 bias4[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        bias4[ct] = *(const f32x4*)(a.bias + ctile * 16 + (lane >> 4) * 4);
+    }
 
     if (loader && n_items > 0) issue_item(0);
     __syncthreads();
@@ -348,7 +414,7 @@ __global__ __launch_bounds__(320) void conv_igemm_f32_v2(ConvKArgs a) {
             if (st == nst - 1) {
                 int b, oy0, ox0;
                 tile_origin(item, b, oy0, ox0);
-                conv_epilogue<STRIDE, PT, CT, WP>(a, acc, lane, wp, ct0, b, oy0, ox0, npix);
+                conv_epilogue<STRIDE, PT, CT, WP>(a, acc, bias4, lane, wp, ct0, b, oy0, ox0, npix);
             }
         }
         __syncthreads();
@@ -387,6 +453,12 @@ __global__ __launch_bounds__(256) void conv1x1_stream_f32(ConvKArgs a) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    f32x4 bias4[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        bias4[ct] = *(const f32x4*)(a.bias + ctile * 16 + g * 4);
+    }
     constexpr int D = 4;                                             // prefetch depth (steps in flight: D-1)
     const int n_it = a.cib;
     // in the last 16-channel block the lanes whose 4 channels lie beyond round_up(Cin, 4) read zeros instead
@@ -433,7 +505,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_f32(ConvKArgs a) {
         for (int ct = 0; ct < CT; ++ct) {
             const int c = (ct0 + ct) * 16 + g * 4;
             if (!ok || c >= a.Cout) continue;
-            f32x4 v = acc[ct][pt] + *(const f32x4*)(a.bias + c);
+            f32x4 v = acc[ct][pt] + bias4[ct];
             if (a.act) {
                 v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
             }
@@ -607,6 +679,7 @@ static const char* check_args(const ConvArgs& c) {
     if ((c.src_cs & 3) || (c.dst_cs & 3) || (c.res && (c.res_cs & 3))) return "conv: channel strides must be multiples of 4";
     if (((uintptr_t)c.src | (uintptr_t)c.dst | (uintptr_t)c.res | (uintptr_t)c.wpk | (uintptr_t)c.bias) & 15)
         return "conv: pointers must be 16-byte aligned";
+    if (!c.zeros) return "conv: zero page missing";
     return nullptr;
 }
 

@@ -820,6 +820,27 @@ int mi355_bench_conv2d(int device_id, int n, int h, int w, int cin, int cout, in
     if (plan_desc && plan_desc_len > 0)
         snprintf(plan_desc, plan_desc_len, "v%d CT%d WP%d tile %dx%d ck%d lds %zu grid %ux%u", l.version, l.CT, l.WP, l.a.TW, l.a.TH, l.a.ck,
                  l.lds, l.grid_x, l.grid_y);
+    if (getenv("MI355_STAMPS") && l.version == 1) {
+        // diagnostic: one stamped launch; prints the mean per-wave phase durations (shader cycles)
+        ConvLaunch ls = l;
+        const size_t nw = (size_t)l.grid_x * l.grid_y * 4;
+        unsigned long long* d_dbg;
+        HIPCHK(dm.alloc(&d_dbg, nw * 6 * 8));
+        HIPCHK(hipMemset(d_dbg, 0, nw * 6 * 8));
+        ls.a.debug = d_dbg;
+        KCHK(run_conv(l, nullptr)); KCHK(run_conv(ls, nullptr));
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hd(nw * 6);
+        HIPCHK(hipMemcpy(hd.data(), d_dbg, nw * 6 * 8, hipMemcpyDeviceToHost));
+        double st = 0, lp = 0, ep = 0, tot = 0, ld = 0, alu = 0, real = 0;
+        for (size_t i = 0; i < nw; ++i) {
+            st += hd[i * 6 + 1]; lp += hd[i * 6 + 2]; ep += hd[i * 6 + 3]; tot += hd[i * 6 + 4];
+            ld += (double)(hd[i * 6 + 0] >> 24); alu += (double)(hd[i * 6 + 0] & 0xffffff); real += (double)hd[i * 6 + 5];
+        }
+        fprintf(stderr, "[stamps] waves %zu  mean cycles per wave: staging %.0f (own loads+LDS writes landed after %.0f, rest = barrier wait)  "
+                        "k-loop %.0f  epilogue %.0f (ALU pass %.0f, rest = store pass incl. acks)  lifetime %.0f  | shader clock %.2f GHz\n",
+                nw, st / nw, ld / nw, lp / nw, ep / nw, alu / nw, tot / nw, tot / real * 0.1);
+    }
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     for (int i = 0; i < 2; ++i) KCHK(run_conv(l, nullptr));
