@@ -5,6 +5,7 @@
 #include "../../include/mi355_yolo.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -114,6 +115,8 @@ struct mi355_yolo {
     float* lut = nullptr;
     float* zeros = nullptr;             // 256 zero bytes: DMA source of padded LDS slots
     int chunk = 64;
+    // tuned launch-plan choice per (frames, H, W): candidate index per op, so a shape seen before is not re-timed
+    std::vector<std::pair<std::array<int, 3>, std::vector<int>>> tuned;
     int autotune = 16;                  // candidate launch plans timed per conv when a shape is first seen (0 = off)
     long long n_params = 0, macs640 = 0;
 
@@ -258,6 +261,10 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
     }
     h->plans.assign(h->ops.size(), ConvLaunch{});
     const bool tune_log = getenv("MI355_TUNE_LOG") != nullptr;
+    const std::array<int, 3> shape_key{nb, Hl, Wl};
+    const std::vector<int>* cached = nullptr;
+    for (const auto& t : h->tuned) if (t.first == shape_key) cached = &t.second;
+    std::vector<int> chosen(h->ops.size(), 0);
     for (size_t i = 0; i < h->ops.size(); ++i) {
         const FileOp& o = h->ops[i];
         if (o.type != OP_CONV) continue;
@@ -274,7 +281,9 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
         std::vector<ConvLaunch> cands;
         KCHK(plan_conv_candidates(a, &cands));
         h->plans[i] = cands[0];
-        if (h->autotune && cands.size() > 1) {
+        if (cached && (size_t)(*cached)[i] < cands.size()) {
+            h->plans[i] = cands[(*cached)[i]];
+        } else if (h->autotune && cands.size() > 1) {
             // Time the most promising launch plans on the real buffers (outputs are overwritten by the next real
             // pass; the accumulation order is plan-independent, so the choice cannot change results).
             const size_t ncand = std::min<size_t>(cands.size(), (size_t)h->autotune);
@@ -290,7 +299,7 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                     HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
                     if (rep > 0) ms = std::min(ms, t);          // first run warms the instruction cache
                 }
-                if (ms < best_ms) { best_ms = ms; h->plans[i] = cands[k]; }
+                if (ms < best_ms) { best_ms = ms; h->plans[i] = cands[k]; chosen[i] = (int)k; }
                 if (tune_log)
                     fprintf(stderr, "[tune] %-22s %4u->%-4u k%u s%u @%dx%d  v%d CT%d WP%d tile %dx%d ck%d lds %zu grid %ux%u : %.1f us  %.1f TFLOP/s\n",
                             c.name, c.cin, c.cout, c.k, c.s, a.Hout, a.Wout, cands[k].version, cands[k].CT, cands[k].WP, cands[k].a.TW,
@@ -301,6 +310,7 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                                   h->plans[i].WP, h->plans[i].a.TW, h->plans[i].a.TH, h->plans[i].a.ck, best_ms * 1e3);
         }
     }
+    if (!cached && h->autotune) h->tuned.push_back({shape_key, chosen});
     int A = 0;
     for (const FileLevel& lv : h->levels) A += (Hl / lv.stride) * (Wl / lv.stride);
     h->A = A; h->Apow2 = 1; while (h->Apow2 < A) h->Apow2 <<= 1;

@@ -230,3 +230,23 @@ def test_bit_exact_other_models_and_sizes(name, n, h, w, imgsz):
     # low threshold: thousands of candidates per image through sort + greedy NMS, max_det cap
     want, _ = det.predict(dm, list(frames[:1]), conf=0.001, imgsz=imgsz)
     _assert_rows_identical(m.predict(frames[:1], conf=0.001, imgsz=imgsz), want, dm.pose)
+
+
+def test_shape_switching_reuses_tuning_and_stays_exact(v8n):
+    """alternating batch sizes / frame sizes: same rows every time (launch plans are cached per shape, and every
+    plan gives the same bits anyway)"""
+    import time
+    from tools import synth
+    m = _model("yolov8n", v8n)
+    a = synth.synthetic_frames(5, 128, 160, seed=1)
+    b = synth.synthetic_frames(2, 96, 96, seed=2)
+    ra = [r.boxes.data.numpy().copy() for r in m.predict(a, conf=0.1, imgsz=160)]
+    rb = [r.boxes.data.numpy().copy() for r in m.predict(b, conf=0.1, imgsz=96)]
+    t0 = time.perf_counter()
+    for _ in range(3):
+        for got, want in zip(m.predict(a, conf=0.1, imgsz=160), ra):
+            np.testing.assert_array_equal(got.boxes.data.numpy(), want)
+        for got, want in zip(m.predict(b, conf=0.1, imgsz=96), rb):
+            np.testing.assert_array_equal(got.boxes.data.numpy(), want)
+        np.testing.assert_array_equal(m.predict(a[:1], conf=0.1, imgsz=160)[0].boxes.data.numpy(), ra[0])
+    assert time.perf_counter() - t0 < 5.0          # six shape switches without re-timing candidates
