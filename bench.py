@@ -90,7 +90,7 @@ def main() -> None:
         res = model._infer_rows(frames, 0.25, 0.7, None, 300, args.size)
         if world > 1:
             rows, counts, _ = res
-            return cdist.gather_rows(rows, counts)
+            return cdist.gather_rows(rows, counts, ncols=7 + model.kpt_shape[0] * model.kpt_shape[1])
         return res
 
     def barrier():

@@ -51,10 +51,14 @@ def broadcast_weights(blob: Optional[bytes], src: int = 0) -> bytes:
     return t.cpu().numpy().tobytes()
 
 
-def gather_rows(rows: np.ndarray, counts: np.ndarray, dst: int = 0):
+def gather_rows(rows: np.ndarray, counts: np.ndarray, dst: int = 0, ncols: Optional[int] = None):
     """C2 + C3.  ``rows`` [B, cap, W] float32 (first counts[i] rows of frame i valid), ``counts`` [B] int32.
+    ``ncols``: ship only the first ncols words of a row (a detect row needs 7 of the 58: box, conf, cls, anchor; a pose
+    row 7 + 51) -- rank 0 receives world x this payload every step, so it is kept minimal.
     On ``dst``: (list over ranks of compact row blocks [sum(counts_r), W], list of counts arrays), in rank
     order == global frame order for contiguous shards.  Other ranks get (None, None)."""
+    if ncols is not None:
+        rows = rows[..., :ncols]
     compact = np.concatenate([rows[i, :c] for i, c in enumerate(counts)], 0) if len(counts) else rows[:0, 0]
     if not is_dist():
         return [compact], [np.asarray(counts)]
