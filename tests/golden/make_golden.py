@@ -1,6 +1,6 @@
 """Generate the committed golden vectors under tests/golden/ (run in the build container; the outputs travel).
 
-    python tools/make_golden.py
+    python tests/golden/make_golden.py
 
 Everything is produced by the oracles (oracle/det.py canonical-order C kernels, oracle/yolo_oracle.py) from seeded
 inputs and the seeded synthetic checkpoints -- the reference ships no fixtures for this path.
@@ -11,7 +11,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import det, yolo_oracle as O  # noqa: E402
 from tools import synth  # noqa: E402

@@ -179,7 +179,7 @@ def test_errors(v8n, tmp_path):
 
 @pytest.mark.parametrize("name", ["yolov8n", "yolov8n-pose"])
 def test_engine_matches_committed_golden_vectors(name):
-    """tests/golden/golden_v1.npz (written in the build container by tools/make_golden.py from the canonical-order
+    """tests/golden/golden_v1.npz (written in the build container by tests/golden/make_golden.py from the canonical-order
     oracle): head tensor of 2 small frames and the post-NMS rows of 2 frames at 640x640 -- bit for bit."""
     import os
     from tools import synth
@@ -250,3 +250,35 @@ def test_shape_switching_reuses_tuning_and_stays_exact(v8n):
             np.testing.assert_array_equal(got.boxes.data.numpy(), want)
         np.testing.assert_array_equal(m.predict(a[:1], conf=0.1, imgsz=160)[0].boxes.data.numpy(), ra[0])
     assert time.perf_counter() - t0 < 5.0          # six shape switches without re-timing candidates
+
+
+def test_full_size_batch_properties(v8n_pose):
+    """BASELINE config 3 at full size (YOLOv8n-pose, batch 32, 640x640): size-independent properties.  Rows of a frame
+    do not depend on the batch it travels in, on its position, or on the engine's chunking; two frames are
+    additionally pinned bit for bit against the canonical-order oracle."""
+    from cvsd_amd import YOLO
+    from oracle import det
+    from tools import synth
+    frames = synth.synthetic_frames(32, 640, 640, seed=77)
+    m = _model("yolov8n-pose", v8n_pose)
+    full = m.predict(frames, conf=0.25)
+    assert len(full) == 32 and sum(len(r) for r in full) > 100
+    again = m.predict(frames, conf=0.25)                                            # idempotent
+    rev = m.predict(frames[::-1].copy(), conf=0.25)                                 # permutation-equivariant
+    small = YOLO.from_state_dict("yolov8n-pose", v8n_pose[1], batch_chunk=5)        # 32 = 6 chunks of 5 + a tail of 2
+    chunked = small.predict(frames, conf=0.25)
+    for i, r in enumerate(full):
+        for other in (again[i], rev[31 - i], chunked[i]):
+            np.testing.assert_array_equal(r.boxes.data.numpy(), other.boxes.data.numpy())
+            np.testing.assert_array_equal(r.keypoints.data.numpy(), other.keypoints.data.numpy())
+            np.testing.assert_array_equal(r.anchor_idx, other.anchor_idx)
+    for i in (0, 17):
+        alone = m.predict(frames[i], conf=0.25)[0]
+        np.testing.assert_array_equal(full[i].boxes.data.numpy(), alone.boxes.data.numpy())
+    want, _ = det.predict(det.DetOracleModel("yolov8n-pose", v8n_pose[1]), [frames[3], frames[30]], conf=0.25)
+    _assert_rows_identical([full[3], full[30]], want, True)
+    # boxes are inside the image, rows are confidence-sorted, at most max_det of them
+    for r in full:
+        b = r.boxes.data.numpy()
+        assert len(b) <= 300 and (np.diff(b[:, 4]) <= 0).all()
+        assert (b[:, :4] >= 0).all() and (b[:, [0, 2]] <= 640).all() and (b[:, [1, 3]] <= 640).all()
