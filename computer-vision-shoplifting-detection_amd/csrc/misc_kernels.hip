@@ -129,10 +129,56 @@ const char* launch_upsample2x(const float* src, int src_cs, float* dst, int dst_
 }
 
 // ---------------------------------------------------------------------------------------------- SPPF pools
-// Three chained MaxPool2d(5, stride 1, pad 2) (block.py:SPPF.forward).  max is exact and pooling with -inf
-// padding composes, so x2 = maxpool9(x0) and x3 = maxpool13(x0): all three are produced from one pass over
-// the 13x13 neighbourhood of x0 (L1/L2-resident: the map is H/32 x W/32).
+// Three chained MaxPool2d(5, stride 1, pad 2) (block.py:SPPF.forward): x1 = pool(x0), x2 = pool(x1), x3 = pool(x2).
+// One block owns (image, 16 channels): the H/32 x W/32 map of those channels lives in LDS and the three pools run
+// back to back on it (25 LDS reads per output float4 and pool, instead of a 13x13 global window).  max is exact.
+
 __global__ __launch_bounds__(256) void sppf_pools_kernel(const float* src, int src_cs, float* dst, int dst_cs,
+                                                         int B, int H, int W, int C, int POOL_C) {
+    extern __shared__ __attribute__((aligned(16))) float pl[];              // two maps [H*W][POOL_C]
+    const int cgroups = (C + POOL_C - 1) / POOL_C;
+    const int b = blockIdx.x / cgroups, c0 = (blockIdx.x % cgroups) * POOL_C;
+    const int npx = H * W, nq = POOL_C / 4;
+    float* cur = pl;
+    float* nxt = pl + (size_t)npx * POOL_C;
+    const float NEG = -__builtin_huge_valf();
+    for (int i = threadIdx.x; i < npx * nq; i += 256) {
+        const int p = i / nq, q = i % nq;
+        f32x4 v = (f32x4){NEG, NEG, NEG, NEG};
+        if (c0 + 4 * q < C) v = *(const f32x4*)(src + ((size_t)b * npx + p) * src_cs + c0 + 4 * q);
+        *(f32x4*)(cur + p * POOL_C + 4 * q) = v;
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int i = threadIdx.x; i < npx * nq; i += 256) {
+            const int p = i / nq, q = i % nq;
+            const int y = p / W, x = p - y * W;
+            f32x4 m = (f32x4){NEG, NEG, NEG, NEG};
+            for (int dy = -2; dy <= 2; ++dy) {
+                const int yy = y + dy;
+                if ((unsigned)yy >= (unsigned)H) continue;
+                for (int dx = -2; dx <= 2; ++dx) {
+                    const int xx = x + dx;
+                    if ((unsigned)xx >= (unsigned)W) continue;
+                    const f32x4 v = *(const f32x4*)(cur + (yy * W + xx) * POOL_C + 4 * q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]);
+                }
+            }
+            *(f32x4*)(nxt + p * POOL_C + 4 * q) = m;
+            if (c0 + 4 * q < C) {
+                float* d = dst + ((size_t)b * npx + p) * dst_cs + pass * C + c0 + 4 * q;
+                if (c0 + 4 * q + 3 < C) *(f32x4*)d = m;
+                else for (int j = 0; c0 + 4 * q + j < C; ++j) d[j] = m[j];
+            }
+        }
+        __syncthreads();
+        float* t = cur; cur = nxt; nxt = t;
+    }
+}
+
+// fallback for maps too large for LDS: 5/9/13-window maxima straight from global memory (max composes exactly)
+__global__ __launch_bounds__(256) void sppf_pools_global_kernel(const float* src, int src_cs, float* dst, int dst_cs,
                                                          int B, int H, int W, int c4n, int C) {
     const long total = (long)B * H * W * c4n;
     const float NEG = -__builtin_huge_valf();
@@ -169,10 +215,20 @@ __global__ __launch_bounds__(256) void sppf_pools_kernel(const float* src, int s
 const char* launch_sppf_pools(const float* src, int src_cs, float* dst, int dst_cs, int B, int H, int W, int C,
                               hipStream_t st) {
     if (C & 3) return "sppf: channel count must be a multiple of 4";
-    const int c4n = C / 4;
-    const long total = (long)B * H * W * c4n;
-    const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(sppf_pools_kernel, dim3(grid), dim3(256), 0, st, src, src_cs, dst, dst_cs, B, H, W, c4n, C);
+    int pc = 0;
+    for (int c = 16; c >= 4; c >>= 1)
+        if ((size_t)2 * H * W * c * sizeof(float) <= 48 * 1024) { pc = c; break; }
+    if (!pc) {
+        const int c4n = C / 4;
+        const long total = (long)B * H * W * c4n;
+        const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL(sppf_pools_global_kernel, dim3(grid), dim3(256), 0, st, src, src_cs, dst, dst_cs, B, H, W, c4n, C);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? nullptr : hipGetErrorString(e);
+    }
+    const size_t lds = (size_t)2 * H * W * pc * sizeof(float);
+    const unsigned grid = (unsigned)(B * ((C + pc - 1) / pc));
+    hipLaunchKernelGGL(sppf_pools_kernel, dim3(grid), dim3(256), lds, st, src, src_cs, dst, dst_cs, B, H, W, C, pc);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
