@@ -138,18 +138,145 @@ __global__ __launch_bounds__(DEC_T) void decode_kernel(DecodeArgs a, int pw) {
     }
 }
 
+// Fast path (4 + nc + nk a multiple of 4, i.e. every standard detect / pose head): same per-anchor arithmetic, but
+// all LDS traffic is 16-byte wide and conflict-free (row pitch = an ODD number of 16-byte slots) and the tile copies use
+// a fixed 16-lanes-per-anchor mapping, so there is no integer division per element.
+template <bool FULL>
+__global__ __launch_bounds__(DEC_T) void decode_kernel_v2(DecodeArgs a, int ps) {      // ps = row pitch in float4 slots (odd)
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int tid = threadIdx.x, sub = tid & 15, rgrp = tid >> 4;                     // 8 row groups of 16 lanes
+    int blk = blockIdx.x;
+    const int b = blk / a.tiles_per_image;
+    blk -= b * a.tiles_per_image;
+    int l = 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        if (j < a.n_levels && blk >= a.tile0[j]) l = j;
+    const HeadLevelArgs lv = a.lv[l];
+    const int hw = lv.H * lv.W;
+    const int li0 = (blk - a.tile0[l]) * DEC_T;
+    const int n_here = min(DEC_T, hw - li0);
+    const float* src = lv.buf + ((size_t)b * hw + li0) * lv.cs;
+    const int nk = a.nkpt * a.kdim, no = 4 + a.nc + nk;
+    const int ncq = (a.nc + 3) >> 2, nkq = (nk + 3) >> 2;
+    const int pw = ps * 4;
+    const int li = li0 + tid;
+    const bool live = tid < n_here;
+    const int y = live ? li / lv.W : 0, x = live ? li - y * lv.W : 0;
+    const float ax = (float)x + 0.5f, ay = (float)y + 0.5f, st = (float)lv.stride;
+    const size_t row = (size_t)b * a.A + lv.anchor0 + li;
+    float* out = a.pred + row * no;
+    float* out0 = a.pred + ((size_t)b * a.A + lv.anchor0 + li0) * no;
+
+    // ---- box: 16 float4 per anchor
+    for (int r = rgrp; r < n_here; r += DEC_T / 16)
+        *(float4*)(tile + r * pw + 4 * sub) = *(const float4*)(src + (size_t)r * lv.cs + lv.box_off + 4 * sub);
+    __syncthreads();
+    if (live) {
+        const float4* t = (const float4*)(tile + tid * pw);
+        float dist[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float4 q4 = t[4 * s + j]; v[4 * j] = q4.x; v[4 * j + 1] = q4.y; v[4 * j + 2] = q4.z; v[4 * j + 3] = q4.w; }
+            float m = v[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) m = fmaxf(m, v[j]);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { v[j] = det_expf(v[j] - m); sum += v[j]; }
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) d += (v[j] / sum) * (float)j;
+            dist[s] = d;
+        }
+        const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
+        float4 o;
+        o.x = ((x1 + x2) / 2.0f) * st;
+        o.y = ((y1 + y2) / 2.0f) * st;
+        o.z = (x2 - x1) * st;
+        o.w = (y2 - y1) * st;
+        *(float4*)out = o;
+    }
+    __syncthreads();
+    // ---- class scores: ncq float4 per anchor (the slice is padded to a multiple of 4 channels in the head buffer)
+    for (int r = rgrp; r < n_here; r += DEC_T / 16)
+        for (int q = sub; q < ncq; q += 16)
+            *(float4*)(tile + r * pw + 4 * q) = *(const float4*)(src + (size_t)r * lv.cs + lv.cls_off + 4 * q);
+    __syncthreads();
+    if (live) {
+        float* t = tile + tid * pw;
+        float best = -1.f; int bi = 0;
+        for (int q = 0; q < ncq; ++q) {
+            float4 v = *(const float4*)(t + 4 * q);
+            float sc[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 4 * q + j;
+                if (c < a.nc) {
+                    sc[j] = det_sigmoid(sc[j]);
+                    if (sc[j] > best) { best = sc[j]; bi = c; }
+                }
+            }
+            if (FULL) *(float4*)(t + 4 * q) = make_float4(sc[0], sc[1], sc[2], sc[3]);
+        }
+        a.best[row] = make_float2(best, (float)bi);
+    }
+    if (FULL) {
+        __syncthreads();
+        for (int r = rgrp; r < n_here; r += DEC_T / 16)
+            for (int c = sub; c < a.nc; c += 16) out0[(size_t)r * no + 4 + c] = tile[r * pw + c];
+    }
+    if (nk == 0) return;
+    // ---- keypoints
+    __syncthreads();
+    for (int r = rgrp; r < n_here; r += DEC_T / 16)
+        for (int q = sub; q < nkq; q += 16)
+            *(float4*)(tile + r * pw + 4 * q) = *(const float4*)(src + (size_t)r * lv.cs + lv.kpt_off + 4 * q);
+    __syncthreads();
+    if (live) {
+        float* t = tile + tid * pw;
+        for (int k = 0; k < a.nkpt; ++k) {
+            float* kp = t + k * a.kdim;
+            kp[0] = (kp[0] * 2.0f + (ax - 0.5f)) * st;
+            kp[1] = (kp[1] * 2.0f + (ay - 0.5f)) * st;
+            if (a.kdim == 3) kp[2] = det_sigmoid(kp[2]);
+        }
+    }
+    __syncthreads();
+    for (int r = rgrp; r < n_here; r += DEC_T / 16)
+        for (int c = sub; c < nk; c += 16) out0[(size_t)r * no + 4 + a.nc + c] = tile[r * pw + c];
+}
+
 const char* launch_decode(const DecodeArgs& a0, bool full, hipStream_t st) {
     DecodeArgs a = a0;
     const int nk = a.nkpt * a.kdim;
     int t = 0;
     for (int l = 0; l < a.n_levels; ++l) { a.tile0[l] = t; t += (a.lv[l].H * a.lv[l].W + DEC_T - 1) / DEC_T; }
     a.tiles_per_image = t;
+    const dim3 grid((unsigned)(a.B * t));
+    bool aligned = ((4 + a.nc + nk) & 3) == 0;
+    for (int l = 0; l < a.n_levels; ++l)
+        aligned = aligned && (a.lv[l].cs & 3) == 0 && (a.lv[l].box_off & 3) == 0 && (a.lv[l].cls_off & 3) == 0 && (a.lv[l].kpt_off & 3) == 0;
+    if (aligned) {
+        int ps = 16;                                              // float4 slots per row: max over the three phases, made odd
+        if ((a.nc + 3) / 4 > ps) ps = (a.nc + 3) / 4;
+        if ((nk + 3) / 4 > ps) ps = (nk + 3) / 4;
+        ps |= 1;
+        const size_t lds2 = (size_t)DEC_T * ps * 16;
+        if (lds2 <= 64 * 1024) {
+            if (full) hipLaunchKernelGGL(decode_kernel_v2<true>, grid, dim3(DEC_T), lds2, st, a, ps);
+            else      hipLaunchKernelGGL(decode_kernel_v2<false>, grid, dim3(DEC_T), lds2, st, a, ps);
+            hipError_t e2 = hipGetLastError();
+            return e2 == hipSuccess ? nullptr : hipGetErrorString(e2);
+        }
+    }
     int pw = 64;
     if (a.nc > pw) pw = a.nc;
     if (nk > pw) pw = nk;
     pw |= 1;
     const size_t lds = (size_t)DEC_T * pw * sizeof(float);
-    const dim3 grid((unsigned)(a.B * t));
     if (full) hipLaunchKernelGGL(decode_kernel<true>, grid, dim3(DEC_T), lds, st, a, pw);
     else      hipLaunchKernelGGL(decode_kernel<false>, grid, dim3(DEC_T), lds, st, a, pw);
     hipError_t e = hipGetLastError();
