@@ -36,6 +36,8 @@ def main() -> None:
     ap.add_argument("--chunk", type=int, default=256, help="engine batch_chunk: frames per pass through the net")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="diagnostic: hand the engine HOST frames each step (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--cpu-frames", type=int, default=8)
     args = ap.parse_args()
 
@@ -86,8 +88,10 @@ def main() -> None:
     frames = torch.from_numpy(frames_np).cuda()
     torch.cuda.synchronize()
 
+    step_src = frames_np if args.host_frames else frames
+
     def step():
-        res = model._infer_rows(frames, 0.25, 0.7, None, 300, args.size)
+        res = model._infer_rows(step_src, 0.25, 0.7, None, 300, args.size)
         if world > 1:
             rows, counts, _ = res
             return cdist.gather_rows(rows, counts, ncols=7 + model.kpt_shape[0] * model.kpt_shape[1])
@@ -147,7 +151,7 @@ def main() -> None:
         with open(tpath) as f:
             traffic = json.load(f)["hbm_bytes_per_launch_avg"]
     line = {
-        "metric": "frames/s @640x640", "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
+        "metric": "frames/s @640x640" + (" (HOST frames, PCIe-inclusive: diagnostic)" if args.host_frames else ""), "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.model} {args.size}x{args.size} synthetic BGR frames, batch {B}/GPU/step, "

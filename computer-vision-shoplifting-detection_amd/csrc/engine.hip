@@ -106,6 +106,8 @@ using namespace mi355;
 struct mi355_yolo {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // H2D of the next chunk overlaps the current chunk's kernels (host-frame entry point)
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
     FileHeader hdr{};
     std::vector<FileBuf> bufs;
     std::vector<FileOp> ops;
@@ -174,6 +176,8 @@ mi355_yolo::~mi355_yolo() {
     if (d_rawhead) (void)hipFree(d_rawhead);
     if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1);
     for (auto e : pev) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) { if (ev_copied[i]) (void)hipEventDestroy(ev_copied[i]); if (ev_consumed[i]) (void)hipEventDestroy(ev_consumed[i]); }
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -511,15 +515,24 @@ static int infer_impl(mi355_yolo* h, const uint8_t* src, bool src_on_device, int
 
     const size_t frame_bytes = (size_t)height * width * 3;
     const uint8_t* dev_frames = src;
+    // Host frames: a double-buffered staging area of two chunks.  Chunk k+1 is copied (on copy_stream) while chunk k's
+    // kernels run; a slot is only overwritten after the kernels that read it (letterbox / stem) have been passed.
+    auto copy_chunk = [&](int s0, int m, int slot) -> int {
+        HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_consumed[slot], 0));
+        HIPCHK(hipMemcpy2DAsync(h->d_in + (size_t)slot * nb * frame_bytes, (size_t)width * 3, src + (size_t)s0 * height * row_stride,
+                                (size_t)row_stride, (size_t)width * 3, (size_t)height * m, hipMemcpyHostToDevice, h->copy_stream));
+        HIPCHK(hipEventRecord(h->ev_copied[slot], h->copy_stream));
+        return MI355_OK;
+    };
     if (!src_on_device) {
-        if (h->d_in_bytes < frame_bytes * n) {
+        if (h->d_in_bytes < frame_bytes * nb * 2) {
             if (h->d_in) (void)hipFree(h->d_in);
             h->d_in = nullptr; h->d_in_bytes = 0;
-            HIPCHK(hipMalloc(&h->d_in, frame_bytes * n)); h->d_in_bytes = frame_bytes * n;
+            HIPCHK(hipMalloc(&h->d_in, frame_bytes * nb * 2)); h->d_in_bytes = frame_bytes * nb * 2;
         }
-        HIPCHK(hipMemcpy2DAsync(h->d_in, (size_t)width * 3, src, (size_t)row_stride, (size_t)width * 3, (size_t)height * n,
-                                hipMemcpyHostToDevice, h->stream));
-        dev_frames = h->d_in;
+        HIPCHK(hipEventRecord(h->ev_consumed[0], h->stream));
+        HIPCHK(hipEventRecord(h->ev_consumed[1], h->stream));
+        rc = copy_chunk(0, std::min(nb, n), 0); if (rc) return rc;
     }
     if (h->rows_cap < (size_t)n * max_det) {
         if (h->d_rows) (void)hipFree(h->d_rows); h->d_rows = nullptr; h->rows_cap = 0;
@@ -554,9 +567,21 @@ static int infer_impl(mi355_yolo* h, const uint8_t* src, bool src_on_device, int
 
     Prof pf{h};
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    for (int s = 0; s < n; s += nb) {
+    for (int s = 0, ci = 0; s < n; s += nb, ++ci) {
         const int m = std::min(nb, n - s);
-        rc = run_chunk(h, pf, dev_frames + (size_t)s * frame_bytes, m, g, false); if (rc) return rc;
+        const uint8_t* chunk_frames = dev_frames + (size_t)s * frame_bytes;
+        if (!src_on_device) {
+            const int slot = ci & 1;
+            HIPCHK(hipStreamWaitEvent(h->stream, h->ev_copied[slot], 0));
+            chunk_frames = h->d_in + (size_t)slot * nb * frame_bytes;
+        }
+        rc = run_chunk(h, pf, chunk_frames, m, g, false); if (rc) return rc;
+        if (!src_on_device) {
+            // the frames of this slot have been consumed once the net's kernels are enqueued behind this event; the
+            // (host-blocking) copy of the next chunk is issued AFTER this chunk's launches so that it overlaps them
+            HIPCHK(hipEventRecord(h->ev_consumed[ci & 1], h->stream));
+            if (s + nb < n) { rc = copy_chunk(s + nb, std::min(nb, n - s - nb), (ci + 1) & 1); if (rc) return rc; }
+        }
         NmsArgs na{};
         na.pred = h->pred; na.best = h->best; na.B = m; na.A = h->A; na.no = h->no(); na.nc = h->hdr.nc;
         na.nk = h->hdr.nkpt * h->hdr.kdim; na.kdim = h->hdr.kdim;
@@ -604,6 +629,11 @@ static int create_impl(const uint8_t* blob, size_t nbytes, int device_id, const 
     if (const char* e = getenv("MI355_GRAPH")) h->use_graph = atoi(e);
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
+    HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_consumed[i], hipEventDisableTiming));
+    }
     const int rc = parse_blob(h.get(), blob, nbytes);
     if (rc) return rc;
     *out = h.release();
