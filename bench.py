@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3        # MI355X fp32 matrix (= vector) peak, /opt/skills/guides/MI355X_MICROARCH.md
+F16_PEAK_TFLOPS = 2500.0        # dense f16 MFMA peak (same guide; the sparsity figure is not used)
 
 
 def main() -> None:
@@ -39,6 +40,9 @@ def main() -> None:
     ap.add_argument("--host-frames", action="store_true",
                     help="diagnostic: hand the engine HOST frames each step (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--half", action="store_true",
+                    help="BASELINE config 5 mode: the half=True engine (fp16 storage, fp32 accumulate); the line then says "
+                         "dtype f16 and prices the convs against the dense f16 MFMA peak.  Never the default headline.")
     args = ap.parse_args()
 
     import torch
@@ -76,7 +80,7 @@ def main() -> None:
         prog, sd = synth.synthetic_checkpoint(args.model, seed=0)
         blob = build_from_state_dict(args.model, sd)
     blob = cdist.broadcast_weights(blob)
-    model = YOLO(blob, device=local_rank, batch_chunk=args.chunk)
+    model = YOLO(blob, device=local_rank, batch_chunk=args.chunk, half=args.half)
     layers, params, _, gflops = model.info()
 
     # ---- synthetic frames of this rank's shard, resident in HBM ----
@@ -147,25 +151,26 @@ def main() -> None:
     # process); only quoted when it was collected on this exact workload
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
-    if os.path.exists(tpath) and args.model == "yolov8n" and args.size == 640 and B == 256 and args.chunk == 256:
+    if os.path.exists(tpath) and args.model == "yolov8n" and args.size == 640 and B == 256 and args.chunk == 256 and not args.half:
         with open(tpath) as f:
             traffic = json.load(f)["hbm_bytes_per_launch_avg"]
+    peak = F16_PEAK_TFLOPS if args.half else FP32_PEAK_TFLOPS
     line = {
-        "metric": "frames/s @640x640" + (" (HOST frames, PCIe-inclusive: diagnostic)" if args.host_frames else ""), "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
+        "metric": f"frames/s @{args.size}x{args.size}" + (" (half=True engine: diagnostic)" if args.half else "") + (" (HOST frames, PCIe-inclusive: diagnostic)" if args.host_frames else ""), "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.half else "f32", "data": "synthetic",
         "config": {"workload": f"{args.model} {args.size}x{args.size} synthetic BGR frames, batch {B}/GPU/step, "
                                f"predict conf=0.25 iou=0.7 max_det=300 (letterbox+stem, conv graph, decode, NMS, rows to host)",
                    "global_batch": B * world, "params": params, "gflop_per_frame": round(gflops * scale, 3),
                    "parallelism": f"frame-sharded dp{world}"},
-        "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (all instances)", "achieved": round(achieved, 2),
-                     "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4),
+        "roofline": {"bound": "mfma", "kernel": ("conv_igemm_f16" if args.half else "conv_igemm_f32") + " (all instances)",
+                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
                      "launches_per_step": launches // PROF_STEPS,
                      "flop_per_launch_avg": conv_flops_frame * B * PROF_STEPS / max(launches, 1)},
         "device_ms_per_step": {k: round(v, 3) for k, v in kinds.items()},
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.half:
         line["cpu_baseline"] = cpu_baseline(args, sd, frames_np, model)
     print(json.dumps(line), flush=True)
     if world > 1:

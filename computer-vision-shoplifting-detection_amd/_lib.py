@@ -18,7 +18,7 @@ class Mi355Error(RuntimeError):
 
 
 class Opts(C.Structure):
-    _fields_ = [("struct_size", C.c_int), ("batch_chunk", C.c_int), ("reserved", C.c_int * 6)]
+    _fields_ = [("struct_size", C.c_int), ("batch_chunk", C.c_int), ("half", C.c_int), ("reserved", C.c_int * 5)]
 
 
 class Det(C.Structure):
@@ -60,7 +60,10 @@ SIGNATURES = {
     "mi355_yolo_last_timing": (C.c_int, [C.c_void_p, _P(Timing)]),
     "mi355_op_conv2d": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, _i32p]),
+    "mi355_op_conv2d_f16": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i32p]),
     "mi355_bench_conv2d": (C.c_int, [C.c_int] * 12 + [_f32p, _i32p, C.c_char_p, C.c_int]),
+    "mi355_bench_conv2d_f16": (C.c_int, [C.c_int] * 12 + [_f32p, _i32p, C.c_char_p, C.c_int]),
     "mi355_op_stem": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_int, C.c_int, C.c_void_p]),
     "mi355_letterbox_shape": (C.c_int, [C.c_int, C.c_int, C.c_int, _i32p, _i32p]),

@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmi355yolo.so")
-SOURCES = ["conv_igemm.hip", "misc_kernels.hip", "post_kernels.hip", "engine.hip"]
+SOURCES = ["conv_igemm.hip", "conv_igemm_f16.hip", "misc_kernels.hip", "post_kernels.hip", "engine.hip"]
 HEADERS = ["common.h", "detmath.h", os.path.join("..", "..", "include", "mi355_yolo.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-result"]
 

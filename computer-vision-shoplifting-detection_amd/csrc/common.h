@@ -20,11 +20,20 @@ struct ConvArgs {
     int Cin, Cout;
     int k, stride, pad, act;           // k in {1,3}; act: 0 none, 1 SiLU
     const float* zeros;                // device pointer to >= 16 zero bytes, or nullptr (then only v1 plans are offered)
+    // half=True path (conv_igemm_f16.hip): dtype 1 = src / res / wpk hold fp16 (pack_conv_weights_f16), strides count halfs;
+    // dst holds fp16 too unless out_f32 (the head's final convs).  The pointers keep their float* type; only bytes matter.
+    int dtype = 0, out_f32 = 0;
 };
 // number of floats pack_conv_weights writes: ceil(cout/16) * k*k * ceil(cin/16) * 256
 size_t packed_weight_floats(int cout, int cin, int k);
 // OIHW fp32 -> MFMA fragment order [cout_tile][tap][cin_block][lane(64)][4]
 void pack_conv_weights(const float* w_oihw, int cout, int cin, int k, float* out);
+// fp16 variant: ceil(cout/16) * k*k * ceil(cin/32) * 512 halfs, [cout_tile][tap][cin_block32][lane(64)][8], RNE from fp32
+size_t packed_weight_halfs(int cout, int cin, int k);
+void pack_conv_weights_f16(const float* w_oihw, int cout, int cin, int k, uint16_t* out_bits);
+void floats_to_halfs(const float* in, uint16_t* out_bits, size_t n);     // round-to-nearest-even
+void halfs_to_floats(const uint16_t* in_bits, float* out, size_t n);
+const void* pick_conv_kernel_f16(int ks, int stride, int CT, int WP, int version, int stream_pt);
 struct ConvKArgs {
     const float* src; float* dst; const float* res; const float* wpk; const float* bias;
     int src_cs, dst_cs, res_cs;
@@ -35,6 +44,7 @@ struct ConvKArgs {
     float inv_TW, inv_TWin;
     int pad, act;
     const float* zeros;        // >= 16 bytes of zeros (source of out-of-image / beyond-Cin slots of the v2 LDS-DMA loader)
+    int out_f32;               // fp16 kernels: destination (and residual) hold fp32
     int lds_buf_floats;        // v2: floats per LDS stage buffer
     int n_tiles_total;         // B * tiles_x * tiles_y (v2 blocks loop over tiles)
     unsigned long long* debug; // diagnostics: per-wave phase stamps (6 words per wave), nullptr in product launches
@@ -54,6 +64,7 @@ struct StemArgs {
     const float* bias;                 // device [Cout]
     const float* lut;                  // device [256]: (float)i / 255.0f
     int B, H, W, Hout, Wout, Cout, k, stride, pad;
+    int out_half = 0;                  // 1: dst holds fp16 (dst_cs counts halfs); arithmetic stays fp32, one rounding on the store
 };
 const char* launch_stem(const StemArgs& a, hipStream_t st);
 const char* launch_upsample2x(const float* src, int src_cs, float* dst, int dst_cs, int B, int H, int W, int C,
@@ -62,6 +73,9 @@ const char* launch_upsample2x(const float* src, int src_cs, float* dst, int dst_
 // dst = slice of 3*C channels receiving x1|x2|x3.
 const char* launch_sppf_pools(const float* src, int src_cs, float* dst, int dst_cs, int B, int H, int W, int C,
                               hipStream_t st);
+// fp16 buffers (strides / C in halfs, C % 8 == 0); max is exact in any precision
+const char* launch_sppf_pools_f16(const void* src, int src_cs, void* dst, int dst_cs, int B, int H, int W, int C,
+                                  hipStream_t st);
 struct LetterboxArgs {
     const uint8_t* src; int H, W; long long frame_stride; int row_stride;   // source frames
     uint8_t* dst; int Hd, Wd;                                               // letterboxed output (dense)

@@ -608,7 +608,7 @@ constexpr size_t LDS_SOFT = 40 * 1024, LDS_HARD = 64 * 1024;
 
 // Candidate launch plans for one conv: for every wave arrangement (CT, WC) the best output tile, with every
 // feasible staged-channel count.  Sorted by a static cost model; the engine may time the first few (autotune).
-std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, int stride, bool allow_v2) {
+std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, int stride, bool allow_v2, bool half) {
     static const int use_v2 = env_int("MI355_CONV_V2", 0);   // the loader-wave kernel never won on this network: opt-in
     static const int max_ct = env_int("MI355_MAX_CT", 5);          // tuning knobs (experiments only)
     static const int min_wc = env_int("MI355_MIN_WC", 1);
@@ -645,7 +645,7 @@ std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, i
                     const int THin = (best.TH - 1) * stride + ks, TWin = (best.TW - 1) * stride + ks;
                     const int buf_floats = round_up(THin * TWin * ck, 256);
                     const size_t lds2 = (size_t)buf_floats * 4 * 2;      // always double-buffered: the pipeline runs across tiles
-                    if (allow_v2 && use_v2 && lds2 <= LDS_HARD) {
+                    if (allow_v2 && use_v2 && !half && lds2 <= LDS_HARD) {
                         Plan v2 = best;
                         v2.version = 2; v2.buf_floats = buf_floats; v2.lds = lds2;
                         v2.cost = best.cost * 0.98 + (lds2 > LDS_SOFT + 24 * 1024 ? 0.1 : 0.0);
@@ -676,6 +676,13 @@ std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, i
 static const char* check_args(const ConvArgs& c) {
     if (!((c.k == 1 && c.stride == 1) || (c.k == 3 && (c.stride == 1 || c.stride == 2))))
         return "conv: only 1x1/s1, 3x3/s1 and 3x3/s2 are supported";
+    if (c.dtype == 1) {     // fp16 storage: 16-byte source vectors = 8 halfs, 8-byte (or fp32 16-byte) destination vectors
+        if ((c.src_cs & 7) || (c.dst_cs & 3) || (c.res && (c.res_cs & 3))) return "conv(f16): channel strides must be multiples of 8 (src) / 4 (dst)";
+        if (((uintptr_t)c.src | (uintptr_t)c.wpk | (uintptr_t)c.bias) & 15) return "conv(f16): src / weight / bias pointers must be 16-byte aligned";
+        if (((uintptr_t)c.dst | (uintptr_t)c.res) & (c.out_f32 ? 15 : 7)) return "conv(f16): dst / residual pointers are misaligned";
+        if (!c.zeros) return "conv: zero page missing";
+        return nullptr;
+    }
     if ((c.src_cs & 3) || (c.dst_cs & 3) || (c.res && (c.res_cs & 3))) return "conv: channel strides must be multiples of 4";
     if (((uintptr_t)c.src | (uintptr_t)c.dst | (uintptr_t)c.res | (uintptr_t)c.wpk | (uintptr_t)c.bias) & 15)
         return "conv: pointers must be 16-byte aligned";
@@ -688,14 +695,18 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     a.src = c.src; a.dst = c.dst; a.res = c.res; a.wpk = c.wpk; a.bias = c.bias;
     a.src_cs = c.src_cs; a.dst_cs = c.dst_cs; a.res_cs = c.res_cs;
     a.Cin = c.Cin; a.Cout = c.Cout; a.pad = c.pad; a.act = c.act;
-    a.cib = (c.Cin + 15) / 16; a.n_ctiles = (c.Cout + 15) / 16; a.cin4 = round_up(c.Cin, 4);
+    const bool half = c.dtype == 1;
+    a.cib = half ? (c.Cin + 31) / 32 : (c.Cin + 15) / 16; a.n_ctiles = (c.Cout + 15) / 16;
+    a.cin4 = half ? round_up(c.Cin, 8) : round_up(c.Cin, 4);       // channels covered by whole 16-byte vectors
+    a.out_f32 = c.out_f32;
     int B = c.B;
     if (c.k == 1) {   // pointwise: flatten batch and space into one row of pixels
         a.Hin = 1; a.Win = c.B * c.Hin * c.Win; a.Hout = 1; a.Wout = a.Win; B = 1;
     } else {
         a.Hin = c.Hin; a.Win = c.Win; a.Hout = c.Hout; a.Wout = c.Wout;
     }
-    KernelFn fn = p.version == 3 ? pick_stream(p.CT, p.buf_floats) : pick_kernel(c.k, c.stride, p.CT, p.WP, p.version);
+    KernelFn fn = half ? (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.buf_floats)
+                       : (p.version == 3 ? pick_stream(p.CT, p.buf_floats) : pick_kernel(c.k, c.stride, p.CT, p.WP, p.version));
     if (!fn) return "conv: no kernel instance";
     a.zeros = c.zeros; a.lds_buf_floats = p.buf_floats;
     a.TW = p.TW; a.TH = p.TH;
@@ -704,7 +715,8 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     const int THin = (p.TH - 1) * c.stride + c.k;
     a.npix_in = a.TWin * THin;
     a.inv_TW = 1.0f / (float)p.TW; a.inv_TWin = 1.0f / (float)a.TWin;
-    a.ck = p.ck; a.ldp = p.ck + 4;
+    // plans count staged channels in 4-byte units; the fp16 kernels stage twice as many channels in the same bytes
+    a.ck = half ? 2 * p.ck : p.ck; a.ldp = half ? a.ck + 8 : a.ck + 4;
     a.ck4_shift = (p.ck == 64 ? 4 : p.ck == 32 ? 3 : 2);
     const int WC = 4 / p.WP;
     out->fn = (const void*)fn;
@@ -734,7 +746,9 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
 const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out) {
     if (const char* e = check_args(c)) return e;
     const int H = c.k == 1 ? 1 : c.Hout, W = c.k == 1 ? c.B * c.Hout * c.Wout : c.Wout;
-    const std::vector<Plan> plans = enumerate_plans(H, W, (c.Cout + 15) / 16, c.Cin, c.k, c.stride, c.zeros != nullptr);
+    const bool half = c.dtype == 1;
+    const std::vector<Plan> plans = enumerate_plans(H, W, (c.Cout + 15) / 16, half ? (c.Cin + 1) / 2 : c.Cin, c.k, c.stride,
+                                                    c.zeros != nullptr, half);
     if (plans.empty()) return "conv: no launch plan fits in LDS";
     for (const Plan& p : plans) {
         ConvLaunch l{};

@@ -1,0 +1,335 @@
+// half=True path: the same fused conv (1x1 / 3x3, stride 1 / 2) + bias + SiLU (+ residual) as conv_igemm.hip with
+// fp16 STORAGE (activations and weights) and fp32 ARITHMETIC: v_mfma_f32_16x16x32_f16 accumulates in fp32, bias / SiLU /
+// residual are applied in fp32 and the result is rounded to fp16 once (round-to-nearest-even) on the store.  The final
+// 1x1 convs of the head write fp32, so the decode / NMS kernels are the fp32 ones.
+//
+// Replaces ultralytics' `half=True` predictor mode (engine/predictor.py: model.half(), im.half()) reached from the
+// reference through model.py:38; BASELINE config 5 (YOLOv8m 1280x1280 fp16).
+//
+// Byte-for-byte the operand layouts are those of the fp32 kernel with "16 floats" replaced by "32 halfs": a k-block is
+// 32 channels = 64 bytes per pixel, lane (p, g) reads the 16 bytes of channels 8g..8g+7 (one ds_read_b128 /
+// global_load_dwordx4) and ONE MFMA consumes what four fp32 MFMAs did.  The sum over a k-block does not depend on how
+// the instruction assigns k to lanes, because both operands use the same assignment.
+#include "common.h"
+#include "detmath.h"
+
+#pragma clang fp contract(off)
+
+namespace mi355 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// bias + SiLU (+ residual) in fp32, one rounding to fp16 (or a plain fp32 store for the head outputs)
+template <int PT, int CT>
+__device__ __forceinline__ void store_tiles_f16(const ConvKArgs& a, f32x4 (&acc)[CT][PT], const f32x4 (&bias4)[CT], int lane,
+                                                int ct0, const size_t (&po)[PT], const bool (&ok)[PT]) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            f32x4 v = acc[ct][pt] + bias4[ct];
+            if (a.act) { v[0] = det_silu(v[0]); v[1] = det_silu(v[1]); v[2] = det_silu(v[2]); v[3] = det_silu(v[3]); }
+            acc[ct][pt] = v;
+        }
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = (ct0 + ct) * 16 + (lane >> 4) * 4;
+            if (!ok[pt] || c >= a.Cout) continue;
+            f32x4 v = acc[ct][pt];
+            if (a.out_f32) {
+                float* d = a.dst + po[pt] * a.dst_cs + c;
+                if (c + 3 < a.Cout) {
+                    if (a.res) v += *(const f32x4*)(a.res + po[pt] * a.res_cs + c);
+                    *(f32x4*)d = v;
+                } else {
+                    for (int i = 0; i < 4 && c + i < a.Cout; ++i) d[i] = v[i] + (a.res ? a.res[po[pt] * a.res_cs + c + i] : 0.f);
+                }
+            } else {
+                _Float16* d = (_Float16*)a.dst + po[pt] * a.dst_cs + c;
+                const _Float16* r = (const _Float16*)a.res + po[pt] * a.res_cs + c;
+                if (c + 3 < a.Cout) {
+                    if (a.res) { const f16x4 rv = *(const f16x4*)r; v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3]; }
+                    f16x4 o;
+                    o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+                    *(f16x4*)d = o;
+                } else {
+                    for (int i = 0; i < 4 && c + i < a.Cout; ++i) d[i] = (_Float16)(v[i] + (a.res ? (float)r[i] : 0.f));
+                }
+            }
+        }
+}
+
+// Block = 256 threads = 4 waves, WP along pixels x WC along couts; a wave owns PT pixel tiles x CT cout tiles of 16x16.
+// The halo tile is staged through LDS in chunks of a.ck channels (a.ck halfs, pixel stride a.ldp = ck + 8 halfs).
+template <int KS, int STRIDE, int PT, int CT, int WP>
+__global__ __launch_bounds__(256) void conv_igemm_f16(ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds_h[];
+    constexpr int WC = 4 / WP;
+    constexpr int TAPS = KS * KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave % WP, wc = wave / WP;
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
+    const int ct0 = (blockIdx.y * WC + wc) * CT;
+    const int npix = a.TW * a.TH;
+    int xoff[PT];
+    size_t po[PT]; bool ok[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int p = (wp * PT + pt) * 16 + (lane & 15);
+        const int pp = p < npix ? p : 0;
+        const int ly = (int)(((float)pp + 0.5f) * a.inv_TW);
+        const int lx = pp - ly * a.TW;
+        xoff[pt] = ((ly * STRIDE) * a.TWin + lx * STRIDE) * a.ldp + (lane >> 4) * 8;
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        ok[pt] = (p < npix) && (oy < a.Hout) && (ox < a.Wout);
+        po[pt] = ((size_t)b * a.Hout + oy) * a.Wout + ox;
+    }
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const _Float16* srcb = (const _Float16*)a.src + (size_t)b * a.Hin * a.Win * a.src_cs;
+    const _Float16* zeros = (const _Float16*)a.zeros;
+    const _Float16* wbase[CT];
+    f32x4 bias4[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);   // padded cout tiles re-read the last one
+        wbase[ct] = (const _Float16*)a.wpk + (size_t)ctile * TAPS * a.cib * 512 + lane * 8;
+        bias4[ct] = *(const f32x4*)(a.bias + ctile * 16 + (lane >> 4) * 4);
+    }
+    const int ck8m = (a.ck >> 3) - 1;
+    const int total_v = a.npix_in << a.ck4_shift;          // 16-byte slots of one staged chunk
+
+    for (int c0 = 0; c0 < a.Cin; c0 += a.ck) {
+        if (c0) __syncthreads();
+        // stage the halo tile, channels [c0, c0+ck): 8 loads per thread in flight, zero page outside the image / beyond Cin
+        for (int base = 0; base < total_v; base += 8 * 256) {
+            f16x8 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int pix = idx >> a.ck4_shift, q = idx & ck8m;
+                const int iy = (int)(((float)pix + 0.5f) * a.inv_TWin);
+                const int ix = pix - iy * a.TWin;
+                const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + 8 * q;
+                const bool inb = idx < total_v && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && c < a.cin4;
+                const _Float16* g = inb ? srcb + ((size_t)gy * a.Win + gx) * a.src_cs + c : zeros;
+                v[u] = *(const f16x8*)g;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                if (idx < total_v) {
+                    const int pix = idx >> a.ck4_shift, q = idx & ck8m;
+                    *(f16x8*)(lds_h + pix * a.ldp + 8 * q) = v[u];
+                }
+            }
+        }
+        __syncthreads();
+        const int rem = a.Cin - c0;
+        const int nkk = ((rem < a.ck ? rem : a.ck) + 31) >> 5;
+        const int cib0 = c0 >> 5;
+        // (k-block, tap) flattened into one loop of pipeline steps; weight fragments (L2) prefetched WD steps ahead, pixel
+        // fragments (LDS) one step ahead; both cursors clamp at the last step so every load is unconditional
+        constexpr int WD = (CT <= 2) ? 4 : 3;
+        const int n_it = nkk * TAPS;
+        const int wstep = a.cib * 512;
+        int w_it = 0, w_kw = 0, w_kh = 0, w_kk = 0, w_off = cib0 * 512;
+        int x_it = 0, x_kw = 0, x_kh = 0, x_kk = 0, x_off = 0;
+        f16x8 wf[WD][CT], xf[2][PT];
+        auto load_w = [&](f16x8* w) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f16x8*)(wbase[ct] + w_off);
+            if (w_it + 1 < n_it) {
+                ++w_it; ++w_kw; w_off += wstep;
+                if (w_kw == KS) {
+                    w_kw = 0; ++w_kh;
+                    if (w_kh == KS) { w_kh = 0; ++w_kk; w_off = (cib0 + w_kk) * 512; }
+                }
+            }
+        };
+        auto load_x = [&](f16x8* x) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) x[pt] = *(const f16x8*)__builtin_assume_aligned(lds_h + xoff[pt] + x_off, 16);
+            if (x_it + 1 < n_it) {
+                ++x_it; ++x_kw; x_off += a.ldp;
+                if (x_kw == KS) {
+                    x_kw = 0; ++x_kh; x_off += (a.TWin - KS) * a.ldp;
+                    if (x_kh == KS) { x_kh = 0; ++x_kk; x_off = x_kk * 32; }
+                }
+            }
+        };
+        auto mma = [&](const f16x8* w, const f16x8* x) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ct], x[pt], acc[ct][pt], 0, 0, 0);
+        };
+#pragma unroll
+        for (int j = 0; j < WD - 1; ++j) load_w(wf[j]);
+        load_x(xf[0]);
+        constexpr int UN = 2 * WD;                          // unroll: a common multiple of the two ring depths
+        for (int it = 0; it < n_it; it += UN) {
+#pragma unroll
+            for (int j = 0; j < UN; ++j) {
+                load_w(wf[(j + WD - 1) % WD]);
+                load_x(xf[(j + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + j < n_it) mma(wf[j % WD], xf[j & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    store_tiles_f16<PT, CT>(a, acc, bias4, lane, ct0, po, ok);
+}
+
+// Streaming pointwise conv (no LDS): every wave reads its pixel fragments straight from global memory in the MFMA
+// B-operand layout (64 contiguous bytes per pixel per 32-channel block), D-deep register ring for pixels and weights.
+template <int PT, int CT>
+__global__ __launch_bounds__(256) void conv1x1_stream_f16(ConvKArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4;
+    const int total = a.Wout;                                        // flattened pixels (Hout == 1)
+    const int tile0 = ((int)blockIdx.x * 4 + wave) * PT;
+    const int ct0 = (int)blockIdx.y * CT;
+    const _Float16* xbase[PT];
+    size_t po[PT]; bool ok[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int p = (tile0 + pt) * 16 + (lane & 15);
+        ok[pt] = p < total;
+        po[pt] = (size_t)(ok[pt] ? p : total - 1);                   // clamp: results of padded pixels are never stored
+        xbase[pt] = (const _Float16*)a.src + po[pt] * a.src_cs + 8 * g;
+    }
+    const _Float16* zeros = (const _Float16*)a.zeros;
+    const _Float16* wbase[CT];
+    f32x4 bias4[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        wbase[ct] = (const _Float16*)a.wpk + (size_t)ctile * a.cib * 512 + lane * 8;
+        bias4[ct] = *(const f32x4*)(a.bias + ctile * 16 + g * 4);
+    }
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int D = 4;
+    const int n_it = a.cib;
+    // lanes whose 8 channels lie beyond round_up(Cin, 8) read the zero page (only possible in the last 32-channel block)
+    const bool tail_oob = (n_it - 1) * 32 + 8 * g >= a.cin4;
+    f16x8 wf[D][CT], xf[D][PT];
+    int l_it = 0;
+    auto load = [&](f16x8* w, f16x8* x) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f16x8*)(wbase[ct] + l_it * 512);
+        const bool oob = tail_oob && (l_it == n_it - 1);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const _Float16* px = oob ? zeros : xbase[pt] + l_it * 32;
+            x[pt] = *(const f16x8*)px;
+        }
+        if (l_it + 1 < n_it) ++l_it;
+    };
+    auto mma = [&](const f16x8* w, const f16x8* x) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+                acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ct], x[pt], acc[ct][pt], 0, 0, 0);
+    };
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) load(wf[j], xf[j]);
+    for (int it = 0; it < n_it; it += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            load(wf[(j + D - 1) % D], xf[(j + D - 1) % D]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + j < n_it) mma(wf[j], xf[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    store_tiles_f16<PT, CT>(a, acc, bias4, lane, ct0, po, ok);
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+size_t packed_weight_halfs(int cout, int cin, int k) {
+    return (size_t)((cout + 15) / 16) * k * k * ((cin + 31) / 32) * 512;
+}
+
+// OIHW fp32 -> fp16 (round-to-nearest-even) in MFMA fragment order [cout_tile][tap][cin_block32][lane(64)][8]
+void pack_conv_weights_f16(const float* w, int cout, int cin, int k, uint16_t* out_bits) {
+    _Float16* out = (_Float16*)out_bits;
+    const int nct = (cout + 15) / 16, cib = (cin + 31) / 32, taps = k * k;
+    for (int ct = 0; ct < nct; ++ct)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int cb = 0; cb < cib; ++cb) {
+                _Float16* o = out + ((size_t)(ct * taps + tap) * cib + cb) * 512;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s = 0; s < 8; ++s) {
+                        const int co = ct * 16 + (lane & 15);
+                        const int ci = cb * 32 + 8 * (lane >> 4) + s;
+                        o[lane * 8 + s] = (co < cout && ci < cin) ? (_Float16)w[((size_t)co * cin + ci) * taps + tap] : (_Float16)0.f;
+                    }
+            }
+}
+
+void floats_to_halfs(const float* in, uint16_t* out_bits, size_t n) {
+    _Float16* o = (_Float16*)out_bits;
+    for (size_t i = 0; i < n; ++i) o[i] = (_Float16)in[i];
+}
+
+void halfs_to_floats(const uint16_t* in_bits, float* out, size_t n) {
+    const _Float16* p = (const _Float16*)in_bits;
+    for (size_t i = 0; i < n; ++i) out[i] = (float)p[i];
+}
+
+namespace {
+
+typedef void (*KernelFn)(ConvKArgs);
+
+template <int KS, int STRIDE>
+KernelFn pick_ct_wp_h(int CT, int WP) {
+#define MI355_CASE(ct, wp) if (CT == ct && WP == wp) return &conv_igemm_f16<KS, STRIDE, (ct == 5 ? 3 : 4), ct, wp>;
+    MI355_CASE(1, 4) MI355_CASE(2, 4) MI355_CASE(3, 4) MI355_CASE(4, 4) MI355_CASE(5, 4)
+    MI355_CASE(1, 2) MI355_CASE(2, 2) MI355_CASE(3, 2) MI355_CASE(4, 2) MI355_CASE(5, 2)
+    MI355_CASE(1, 1) MI355_CASE(2, 1) MI355_CASE(3, 1) MI355_CASE(4, 1) MI355_CASE(5, 1)
+#undef MI355_CASE
+    return nullptr;
+}
+
+}  // namespace
+
+const void* pick_conv_kernel_f16(int ks, int stride, int CT, int WP, int version, int stream_pt) {
+    if (version == 3) {
+        if (CT == 1 && stream_pt == 2) return (const void*)&conv1x1_stream_f16<2, 1>;
+        if (CT == 1 && stream_pt == 4) return (const void*)&conv1x1_stream_f16<4, 1>;
+        if (CT == 2 && stream_pt == 2) return (const void*)&conv1x1_stream_f16<2, 2>;
+        if (CT == 2 && stream_pt == 4) return (const void*)&conv1x1_stream_f16<4, 2>;
+        if (CT == 4 && stream_pt == 2) return (const void*)&conv1x1_stream_f16<2, 4>;
+        if (CT == 4 && stream_pt == 4) return (const void*)&conv1x1_stream_f16<4, 4>;
+        return nullptr;
+    }
+    if (version != 1) return nullptr;
+    if (ks == 1 && stride == 1) return (const void*)pick_ct_wp_h<1, 1>(CT, WP);
+    if (ks == 3 && stride == 1) return (const void*)pick_ct_wp_h<3, 1>(CT, WP);
+    if (ks == 3 && stride == 2) return (const void*)pick_ct_wp_h<3, 2>(CT, WP);
+    return nullptr;
+}
+
+}  // namespace mi355

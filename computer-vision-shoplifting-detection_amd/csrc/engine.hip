@@ -124,8 +124,11 @@ struct mi355_yolo {
 
     // per-shape state
     int cur_nb = 0, cur_H = 0, cur_W = 0;
-    std::vector<float*> dbuf;           // activation buffers
-    std::vector<int> dbuf_cs;
+    std::vector<float*> dbuf;           // activation buffers (fp32, or fp16 bytes behind a float* when `half`)
+    std::vector<int> dbuf_cs;           // pixel stride in ELEMENTS of the buffer's dtype
+    std::vector<int> dbuf_es;           // element size in bytes: 4, or 2 for the fp16 buffers of the half=True path
+    bool half = false;                  // opts.half: fp16 storage of activations / weights, fp32 arithmetic (conv_igemm_f16.hip)
+    float* view(int buf, int choff) const { return (float*)((char*)dbuf[buf] + (size_t)choff * dbuf_es[buf]); }
     std::vector<ConvLaunch> plans;      // per op (valid for OP_CONV)
     float* pred = nullptr; float2* best = nullptr; unsigned long long* keys = nullptr;
     int A = 0, Apow2 = 0;
@@ -155,7 +158,7 @@ void mi355_yolo::free_shape() {
     for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
     graphs.clear();
     for (float* p : dbuf) if (p) (void)hipFree(p);
-    dbuf.clear(); dbuf_cs.clear(); plans.clear();
+    dbuf.clear(); dbuf_cs.clear(); dbuf_es.clear(); plans.clear();
     if (pred) (void)hipFree(pred); if (best) (void)hipFree(best); if (keys) (void)hipFree(keys);
     if (lbox) (void)hipFree(lbox);
     pred = nullptr; best = nullptr; keys = nullptr; lbox = nullptr;
@@ -233,6 +236,12 @@ static int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
         if (c.cin == 3) {                      // stem: raw OIHW, read by stem_conv_u8
             HIPCHK(hipMalloc(&d.w_raw, wn * 4));
             HIPCHK(hipMemcpy(d.w_raw, w, wn * 4, hipMemcpyHostToDevice));
+        } else if (h->half) {
+            const size_t pn = packed_weight_halfs(c.cout, c.cin, c.k);
+            std::vector<uint16_t> th(pn);
+            pack_conv_weights_f16(w, c.cout, c.cin, c.k, th.data());
+            HIPCHK(hipMalloc(&d.wpk, pn * 2));
+            HIPCHK(hipMemcpy(d.wpk, th.data(), pn * 2, hipMemcpyHostToDevice));
         } else {
             const size_t pn = packed_weight_floats(c.cout, c.cin, c.k);
             tmp.resize(pn);
@@ -255,10 +264,16 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
     h->free_shape();
     if ((Hl % 32) || (Wl % 32)) return fail(MI355_EINVAL, "letterboxed size must be a multiple of 32");
     const size_t nbufs = h->bufs.size();
-    h->dbuf.assign(nbufs, nullptr); h->dbuf_cs.assign(nbufs, 0);
+    h->dbuf.assign(nbufs, nullptr); h->dbuf_cs.assign(nbufs, 0); h->dbuf_es.assign(nbufs, 4);
     for (size_t i = 0; i < nbufs; ++i) {
-        const int cs = round_up((int)h->bufs[i].channels, 4);
-        const size_t bytes = (size_t)nb * (Hl / h->bufs[i].stride_div) * (Wl / h->bufs[i].stride_div) * cs * 4;
+        // half=True: every buffer holds fp16 except the head outputs (raw box / class / keypoint logits), which the
+        // final 1x1 convs write in fp32 for the decode kernel
+        bool is_head = false;
+        for (const FileLevel& lv : h->levels) is_head |= (lv.buf == i);
+        const int es = (h->half && !is_head) ? 2 : 4;
+        const int cs = round_up((int)h->bufs[i].channels, 16 / es);
+        h->dbuf_es[i] = es;
+        const size_t bytes = (size_t)nb * (Hl / h->bufs[i].stride_div) * (Wl / h->bufs[i].stride_div) * cs * es;
         HIPCHK(hipMalloc(&h->dbuf[i], bytes));
         HIPCHK(hipMemsetAsync(h->dbuf[i], 0, bytes, h->stream));   // pad channels stay zero forever
         h->dbuf_cs[i] = cs;
@@ -275,9 +290,14 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
         const FileConv& c = h->convs[o.conv];
         ConvArgs a{};
         const int sd_in = h->bufs[o.src_buf].stride_div, sd_out = h->bufs[o.dst_buf].stride_div;
-        a.src = h->dbuf[o.src_buf] + o.src_choff; a.src_cs = h->dbuf_cs[o.src_buf];
-        a.dst = h->dbuf[o.dst_buf] + o.dst_choff; a.dst_cs = h->dbuf_cs[o.dst_buf];
-        if (o.res_buf >= 0) { a.res = h->dbuf[o.res_buf] + o.res_choff; a.res_cs = h->dbuf_cs[o.res_buf]; }
+        a.src = h->view(o.src_buf, o.src_choff); a.src_cs = h->dbuf_cs[o.src_buf];
+        a.dst = h->view(o.dst_buf, o.dst_choff); a.dst_cs = h->dbuf_cs[o.dst_buf];
+        if (o.res_buf >= 0) { a.res = h->view(o.res_buf, o.res_choff); a.res_cs = h->dbuf_cs[o.res_buf]; }
+        if (h->half) {
+            a.dtype = 1; a.out_f32 = h->dbuf_es[o.dst_buf] == 4;
+            if (h->dbuf_es[o.src_buf] != 2 || (o.res_buf >= 0 && h->dbuf_es[o.res_buf] != h->dbuf_es[o.dst_buf]))
+                return fail(MI355_EFORMAT, "half: a conv reads a head output buffer");
+        }
         a.wpk = h->dconv[o.conv].wpk; a.bias = h->dconv[o.conv].bias; a.zeros = h->zeros;
         a.B = nb; a.Hin = Hl / sd_in; a.Win = Wl / sd_in; a.Hout = Hl / sd_out; a.Wout = Wl / sd_out;
         a.Cin = c.cin; a.Cout = c.cout; a.k = c.k; a.stride = c.s; a.pad = c.pad; a.act = c.act;
@@ -388,7 +408,7 @@ static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, c
     for (size_t i = 0; i < h->ops.size(); ++i) {
         const FileOp& o = h->ops[i];
         const int sd_out = h->bufs[o.dst_buf].stride_div;
-        float* dst = h->dbuf[o.dst_buf] + o.dst_choff;
+        float* dst = h->view(o.dst_buf, o.dst_choff);
         if (o.type == OP_STEM) {
             const FileConv& c = h->convs[o.conv];
             StemArgs s{};
@@ -396,6 +416,7 @@ static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, c
             s.w = h->dconv[o.conv].w_raw; s.bias = h->dconv[o.conv].bias; s.lut = h->lut;
             s.B = nb; s.H = g.Hl; s.W = g.Wl; s.Hout = g.Hl / sd_out; s.Wout = g.Wl / sd_out;
             s.Cout = c.cout; s.k = c.k; s.stride = c.s; s.pad = c.pad;
+            s.out_half = h->dbuf_es[o.dst_buf] == 2;
             if (pf.begin(K_STEM)) return fail(MI355_EHIP, "event");
             KCHK(launch_stem(s, h->stream));
             pf.end();
@@ -429,14 +450,22 @@ static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, c
         } else if (o.type == OP_UPSAMPLE) {
             const int sd_in = h->bufs[o.src_buf].stride_div;
             if (pf.begin(K_UPSAMPLE)) return fail(MI355_EHIP, "event");
-            KCHK(launch_upsample2x(h->dbuf[o.src_buf] + o.src_choff, h->dbuf_cs[o.src_buf], dst, h->dbuf_cs[o.dst_buf], nb,
-                                   g.Hl / sd_in, g.Wl / sd_in, o.src_c, h->stream));
+            if (h->dbuf_es[o.src_buf] != h->dbuf_es[o.dst_buf]) return fail(MI355_EFORMAT, "upsample between buffers of different precision");
+            // fp16 buffers: a pure copy, so two halfs travel as one float (channel counts / offsets are multiples of 8)
+            const int dv = h->dbuf_es[o.src_buf] == 2 ? 2 : 1;
+            if (o.src_c % dv) return fail(MI355_EFORMAT, "half: odd channel count in upsample");
+            KCHK(launch_upsample2x(h->view(o.src_buf, o.src_choff), h->dbuf_cs[o.src_buf] / dv, dst, h->dbuf_cs[o.dst_buf] / dv, nb,
+                                   g.Hl / sd_in, g.Wl / sd_in, o.src_c / dv, h->stream));
             pf.end();
         } else if (o.type == OP_SPPF_POOL) {
             if (o.k != 5) return fail(MI355_EFORMAT, "SPPF pool size must be 5");
             if (pf.begin(K_POOL)) return fail(MI355_EHIP, "event");
-            KCHK(launch_sppf_pools(h->dbuf[o.src_buf] + o.src_choff, h->dbuf_cs[o.src_buf], dst, h->dbuf_cs[o.dst_buf], nb,
-                                   g.Hl / sd_out, g.Wl / sd_out, o.src_c, h->stream));
+            if (h->dbuf_es[o.src_buf] == 2)
+                KCHK(launch_sppf_pools_f16(h->view(o.src_buf, o.src_choff), h->dbuf_cs[o.src_buf], dst, h->dbuf_cs[o.dst_buf], nb,
+                                           g.Hl / sd_out, g.Wl / sd_out, o.src_c, h->stream));
+            else
+                KCHK(launch_sppf_pools(h->view(o.src_buf, o.src_choff), h->dbuf_cs[o.src_buf], dst, h->dbuf_cs[o.dst_buf], nb,
+                                       g.Hl / sd_out, g.Wl / sd_out, o.src_c, h->stream));
             pf.end();
         } else {
             return fail(MI355_EFORMAT, "unknown op type in program");
@@ -625,6 +654,7 @@ static int create_impl(const uint8_t* blob, size_t nbytes, int device_id, const 
     std::unique_ptr<mi355_yolo> h(new mi355_yolo());
     h->device = device_id;
     if (opts && opts->struct_size >= (int)sizeof(mi355_opts) && opts->batch_chunk > 0) h->chunk = opts->batch_chunk;
+    if (opts && opts->struct_size >= (int)sizeof(mi355_opts)) h->half = opts->half != 0;
     if (const char* e = getenv("MI355_AUTOTUNE")) h->autotune = std::max(0, atoi(e));
     if (const char* e = getenv("MI355_GRAPH")) h->use_graph = atoi(e);
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -783,75 +813,126 @@ int mi355_op_letterbox(int device_id, const uint8_t* bgr, int n, int height, int
     return MI355_OK;
 }
 
-int mi355_op_conv2d(int device_id, const float* x, int n, int h, int w, int cin, const float* w_oihw, const float* bias,
-                    int cout, int k, int stride, int silu, const float* residual, float* y, int plan_index, int* n_plans) {
+static int op_conv2d_impl(int device_id, const float* x, int n, int h, int w, int cin, const float* w_oihw, const float* bias,
+                          int cout, int k, int stride, int silu, const float* residual, float* y, int plan_index, int* n_plans,
+                          bool half, bool out_f32) {
     if (!x || !w_oihw || !bias || !y || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return fail(MI355_EINVAL, "bad argument");
     if (!((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)))) return fail(MI355_EINVAL, "k/stride not supported");
     if ((h % stride) || (w % stride)) return fail(MI355_EINVAL, "h and w must be multiples of the stride");
     HIPCHK(hipSetDevice(device_id));
     const int ho = h / stride, wo = w / stride;
-    const int cs_in = round_up(cin, 4), cs_out = round_up(cout, 4);
+    const int es_in = half ? 2 : 4, es_out = (half && !out_f32) ? 2 : 4;
+    const int cs_in = round_up(cin, 16 / es_in), cs_out = round_up(cout, 16 / es_out);
     const size_t npi = (size_t)n * h * w, npo = (size_t)n * ho * wo;
+    // host images of the padded NHWC tensors, in the device dtype (fp32 -> fp16 is round-to-nearest-even)
     std::vector<float> xin(npi * cs_in, 0.f), yout(npo * cs_out, 0.f), rs;
     for (size_t p = 0; p < npi; ++p) std::memcpy(&xin[p * cs_in], x + p * cin, (size_t)cin * 4);
+    auto upload = [&](float** dptr, DevMem& dm, const std::vector<float>& v, int es) -> int {
+        HIPCHK(dm.alloc(dptr, v.size() * es));
+        if (es == 4) { HIPCHK(hipMemcpy(*dptr, v.data(), v.size() * 4, hipMemcpyHostToDevice)); return MI355_OK; }
+        std::vector<uint16_t> hb(v.size());
+        floats_to_halfs(v.data(), hb.data(), v.size());
+        HIPCHK(hipMemcpy(*dptr, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+        return MI355_OK;
+    };
     DevMem dm; float *d_x, *d_y, *d_r = nullptr, *d_w, *d_b, *d_z;
     HIPCHK(dm.alloc(&d_z, 256)); HIPCHK(hipMemset(d_z, 0, 256));
-    HIPCHK(dm.alloc(&d_x, xin.size() * 4)); HIPCHK(dm.alloc(&d_y, yout.size() * 4));
-    HIPCHK(hipMemcpy(d_x, xin.data(), xin.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(d_y, 0, yout.size() * 4));
+    int rc = upload(&d_x, dm, xin, es_in); if (rc) return rc;
+    HIPCHK(dm.alloc(&d_y, yout.size() * es_out));
+    HIPCHK(hipMemset(d_y, 0, yout.size() * es_out));
     if (residual) {
         rs.assign(npo * cs_out, 0.f);
         for (size_t p = 0; p < npo; ++p) std::memcpy(&rs[p * cs_out], residual + p * cout, (size_t)cout * 4);
-        HIPCHK(dm.alloc(&d_r, rs.size() * 4));
-        HIPCHK(hipMemcpy(d_r, rs.data(), rs.size() * 4, hipMemcpyHostToDevice));
+        rc = upload(&d_r, dm, rs, es_out); if (rc) return rc;
     }
-    std::vector<float> pk(packed_weight_floats(cout, cin, k)), bp(round_up(cout, 16), 0.f);
-    pack_conv_weights(w_oihw, cout, cin, k, pk.data());
+    std::vector<float> bp(round_up(cout, 16), 0.f);
     std::memcpy(bp.data(), bias, (size_t)cout * 4);
-    HIPCHK(dm.alloc(&d_w, pk.size() * 4)); HIPCHK(dm.alloc(&d_b, bp.size() * 4));
-    HIPCHK(hipMemcpy(d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(dm.alloc(&d_b, bp.size() * 4));
     HIPCHK(hipMemcpy(d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+    if (half) {
+        std::vector<uint16_t> pk(packed_weight_halfs(cout, cin, k));
+        pack_conv_weights_f16(w_oihw, cout, cin, k, pk.data());
+        HIPCHK(dm.alloc(&d_w, pk.size() * 2));
+        HIPCHK(hipMemcpy(d_w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> pk(packed_weight_floats(cout, cin, k));
+        pack_conv_weights(w_oihw, cout, cin, k, pk.data());
+        HIPCHK(dm.alloc(&d_w, pk.size() * 4));
+        HIPCHK(hipMemcpy(d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+    }
     ConvArgs a{};
     a.src = d_x; a.src_cs = cs_in; a.dst = d_y; a.dst_cs = cs_out; a.res = d_r; a.res_cs = cs_out; a.wpk = d_w; a.bias = d_b;
     a.B = n; a.Hin = h; a.Win = w; a.Hout = ho; a.Wout = wo; a.Cin = cin; a.Cout = cout; a.k = k; a.stride = stride; a.pad = k / 2; a.act = silu ? 1 : 0;
-    a.zeros = d_z;
+    a.zeros = d_z; a.dtype = half ? 1 : 0; a.out_f32 = (half && out_f32) ? 1 : 0;
     std::vector<ConvLaunch> cands;
     KCHK(plan_conv_candidates(a, &cands));
-    // plan_index: which candidate launch plan to run (tests sweep it to cover v1 and v2 kernels and all wave shapes)
+    // plan_index: which candidate launch plan to run (tests sweep it to cover every kernel variant and wave shape)
     const ConvLaunch& l = cands[(size_t)(plan_index < 0 ? 0 : plan_index) % cands.size()];
     if (n_plans) *n_plans = (int)cands.size();
     KCHK(run_conv(l, nullptr));
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(yout.data(), d_y, yout.size() * 4, hipMemcpyDeviceToHost));
+    if (es_out == 4) {
+        HIPCHK(hipMemcpy(yout.data(), d_y, yout.size() * 4, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<uint16_t> hb(yout.size());
+        HIPCHK(hipMemcpy(hb.data(), d_y, hb.size() * 2, hipMemcpyDeviceToHost));
+        halfs_to_floats(hb.data(), yout.data(), hb.size());
+    }
     for (size_t p = 0; p < npo; ++p) std::memcpy(y + p * cout, &yout[p * cs_out], (size_t)cout * 4);
     return MI355_OK;
 }
 
-int mi355_bench_conv2d(int device_id, int n, int h, int w, int cin, int cout, int k, int stride, int silu, int residual,
-                       int plan_index, int iters, float* avg_ms, int* n_plans, char* plan_desc, int plan_desc_len) {
+int mi355_op_conv2d(int device_id, const float* x, int n, int h, int w, int cin, const float* w_oihw, const float* bias,
+                    int cout, int k, int stride, int silu, const float* residual, float* y, int plan_index, int* n_plans) {
+    return op_conv2d_impl(device_id, x, n, h, w, cin, w_oihw, bias, cout, k, stride, silu, residual, y, plan_index, n_plans, false, false);
+}
+
+int mi355_op_conv2d_f16(int device_id, const float* x, int n, int h, int w, int cin, const float* w_oihw, const float* bias,
+                        int cout, int k, int stride, int silu, const float* residual, float* y, int out_f32, int plan_index,
+                        int* n_plans) {
+    return op_conv2d_impl(device_id, x, n, h, w, cin, w_oihw, bias, cout, k, stride, silu, residual, y, plan_index, n_plans, true,
+                          out_f32 != 0);
+}
+
+static int bench_conv2d_impl(int device_id, int n, int h, int w, int cin, int cout, int k, int stride, int silu, int residual,
+                             int plan_index, int iters, float* avg_ms, int* n_plans, char* plan_desc, int plan_desc_len, bool half) {
     if (!avg_ms || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || iters <= 0) return fail(MI355_EINVAL, "bad argument");
     if (!((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)))) return fail(MI355_EINVAL, "k/stride not supported");
     HIPCHK(hipSetDevice(device_id));
-    const int ho = h / stride, wo = w / stride, cs_in = round_up(cin, 4), cs_out = round_up(cout, 4);
-    const size_t nin = (size_t)n * h * w * cs_in, nout = (size_t)n * ho * wo * cs_out;
+    const int es = half ? 2 : 4;
+    const int ho = h / stride, wo = w / stride, cs_in = round_up(cin, 16 / es), cs_out = round_up(cout, 16 / es);
+    const size_t nin = (size_t)n * h * w * cs_in, nout = (size_t)n * ho * wo * cs_out;     // elements
     DevMem dm; float *d_x, *d_y, *d_r = nullptr, *d_w, *d_b, *d_z;
-    HIPCHK(dm.alloc(&d_x, nin * 4)); HIPCHK(dm.alloc(&d_y, nout * 4)); HIPCHK(dm.alloc(&d_z, 256)); HIPCHK(hipMemset(d_z, 0, 256));
+    HIPCHK(dm.alloc(&d_x, nin * es)); HIPCHK(dm.alloc(&d_y, nout * es)); HIPCHK(dm.alloc(&d_z, 256)); HIPCHK(hipMemset(d_z, 0, 256));
     {   // random activations / weights (benchmarks on zeros read high: DVFS)
         std::vector<float> hx(std::min<size_t>(nin, 1u << 22));
+        std::vector<uint16_t> hh(half ? hx.size() : 0);
         unsigned st = 12345u;
         for (float& v : hx) { st = st * 1664525u + 1013904223u; v = ((st >> 8) & 0xffff) / 32768.0f - 1.0f; }
+        if (half) floats_to_halfs(hx.data(), hh.data(), hx.size());
+        const void* hsrc = half ? (const void*)hh.data() : (const void*)hx.data();
         for (size_t o = 0; o < nin; o += hx.size())
-            HIPCHK(hipMemcpy(d_x + o, hx.data(), std::min(hx.size(), nin - o) * 4, hipMemcpyHostToDevice));
-        if (residual) { HIPCHK(dm.alloc(&d_r, nout * 4)); HIPCHK(hipMemcpy(d_r, d_x, std::min(nin, nout) * 4, hipMemcpyDeviceToDevice)); }
-        std::vector<float> wt((size_t)cout * cin * k * k), pk(packed_weight_floats(cout, cin, k)), bp(round_up(cout, 16), 0.1f);
+            HIPCHK(hipMemcpy((char*)d_x + o * es, hsrc, std::min(hx.size(), nin - o) * es, hipMemcpyHostToDevice));
+        if (residual) { HIPCHK(dm.alloc(&d_r, nout * es)); HIPCHK(hipMemcpy(d_r, d_x, std::min(nin, nout) * es, hipMemcpyDeviceToDevice)); }
+        std::vector<float> wt((size_t)cout * cin * k * k), bp(round_up(cout, 16), 0.1f);
         for (float& v : wt) { st = st * 1664525u + 1013904223u; v = (((st >> 8) & 0xffff) / 32768.0f - 1.0f) / std::sqrt((float)cin * k * k); }
-        pack_conv_weights(wt.data(), cout, cin, k, pk.data());
-        HIPCHK(dm.alloc(&d_w, pk.size() * 4)); HIPCHK(dm.alloc(&d_b, bp.size() * 4));
-        HIPCHK(hipMemcpy(d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+        if (half) {
+            std::vector<uint16_t> pk(packed_weight_halfs(cout, cin, k));
+            pack_conv_weights_f16(wt.data(), cout, cin, k, pk.data());
+            HIPCHK(dm.alloc(&d_w, pk.size() * 2));
+            HIPCHK(hipMemcpy(d_w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+        } else {
+            std::vector<float> pk(packed_weight_floats(cout, cin, k));
+            pack_conv_weights(wt.data(), cout, cin, k, pk.data());
+            HIPCHK(dm.alloc(&d_w, pk.size() * 4));
+            HIPCHK(hipMemcpy(d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+        }
+        HIPCHK(dm.alloc(&d_b, bp.size() * 4));
         HIPCHK(hipMemcpy(d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
     }
     ConvArgs a{};
     a.src = d_x; a.src_cs = cs_in; a.dst = d_y; a.dst_cs = cs_out; a.res = d_r; a.res_cs = cs_out; a.wpk = d_w; a.bias = d_b; a.zeros = d_z;
+    a.dtype = half ? 1 : 0;
     a.B = n; a.Hin = h; a.Win = w; a.Hout = ho; a.Wout = wo; a.Cin = cin; a.Cout = cout; a.k = k; a.stride = stride; a.pad = k / 2; a.act = silu ? 1 : 0;
     std::vector<ConvLaunch> cands;
     KCHK(plan_conv_candidates(a, &cands));
@@ -860,7 +941,7 @@ int mi355_bench_conv2d(int device_id, int n, int h, int w, int cin, int cout, in
     if (plan_desc && plan_desc_len > 0)
         snprintf(plan_desc, plan_desc_len, "v%d CT%d WP%d tile %dx%d ck%d lds %zu grid %ux%u", l.version, l.CT, l.WP, l.a.TW, l.a.TH, l.a.ck,
                  l.lds, l.grid_x, l.grid_y);
-    if (getenv("MI355_STAMPS") && l.version == 1) {
+    if (getenv("MI355_STAMPS") && l.version == 1 && !half) {
         // diagnostic: one stamped launch; prints the mean per-wave phase durations (shader cycles)
         ConvLaunch ls = l;
         const size_t nw = (size_t)l.grid_x * l.grid_y * 4;
@@ -893,6 +974,18 @@ int mi355_bench_conv2d(int device_id, int n, int h, int w, int cin, int cout, in
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *avg_ms = ms / iters;
     return MI355_OK;
+}
+
+int mi355_bench_conv2d(int device_id, int n, int h, int w, int cin, int cout, int k, int stride, int silu, int residual,
+                       int plan_index, int iters, float* avg_ms, int* n_plans, char* plan_desc, int plan_desc_len) {
+    return bench_conv2d_impl(device_id, n, h, w, cin, cout, k, stride, silu, residual, plan_index, iters, avg_ms, n_plans, plan_desc,
+                             plan_desc_len, false);
+}
+
+int mi355_bench_conv2d_f16(int device_id, int n, int h, int w, int cin, int cout, int k, int stride, int silu, int residual,
+                           int plan_index, int iters, float* avg_ms, int* n_plans, char* plan_desc, int plan_desc_len) {
+    return bench_conv2d_impl(device_id, n, h, w, cin, cout, k, stride, silu, residual, plan_index, iters, avg_ms, n_plans, plan_desc,
+                             plan_desc_len, true);
 }
 
 int mi355_op_stem(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias, int cout,

@@ -8,6 +8,8 @@
 namespace mi355 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float silu_m(float v) { return det_silu(v); }
 
@@ -75,6 +77,18 @@ __global__ __launch_bounds__(256) void stem_conv_u8(StemArgs a) {
                 }
             }
         const int c = 4 * q;
+        if (a.out_half) {
+            _Float16* dh = (_Float16*)a.dst + (((size_t)b * a.Hout + oy) * a.Wout + ox) * a.dst_cs + c;
+            if (c + 3 < a.Cout) {
+                f16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (_Float16)silu_m(acc[j] + a.bias[c + j]);
+                *(f16x4*)dh = o;
+            } else {
+                for (int j = 0; j < 4 && c + j < a.Cout; ++j) dh[j] = (_Float16)silu_m(acc[j] + a.bias[c + j]);
+            }
+            continue;
+        }
         float* d = a.dst + (((size_t)b * a.Hout + oy) * a.Wout + ox) * a.dst_cs + c;
         if (c + 3 < a.Cout) {
             f32x4 o;
@@ -229,6 +243,107 @@ const char* launch_sppf_pools(const float* src, int src_cs, float* dst, int dst_
     const size_t lds = (size_t)2 * H * W * pc * sizeof(float);
     const unsigned grid = (unsigned)(B * ((C + pc - 1) / pc));
     hipLaunchKernelGGL(sppf_pools_kernel, dim3(grid), dim3(256), lds, st, src, src_cs, dst, dst_cs, B, H, W, C, pc);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+// fp16 variants of the two pool kernels: 8 channels per 16-byte vector
+__device__ __forceinline__ f16x8 max8(f16x8 a, f16x8 b) {
+    f16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = b[j] > a[j] ? b[j] : a[j];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void sppf_pools_f16_kernel(const _Float16* src, int src_cs, _Float16* dst, int dst_cs,
+                                                             int B, int H, int W, int C, int POOL_C) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 plh[];          // two maps [H*W][POOL_C]
+    const int cgroups = (C + POOL_C - 1) / POOL_C;
+    const int b = blockIdx.x / cgroups, c0 = (blockIdx.x % cgroups) * POOL_C;
+    const int npx = H * W, nq = POOL_C / 8;
+    _Float16* cur = plh;
+    _Float16* nxt = plh + (size_t)npx * POOL_C;
+    const _Float16 NEG = (_Float16)(-__builtin_huge_valf());
+    const f16x8 NEG8 = (f16x8){NEG, NEG, NEG, NEG, NEG, NEG, NEG, NEG};
+    for (int i = threadIdx.x; i < npx * nq; i += 256) {
+        const int p = i / nq, q = i % nq;
+        f16x8 v = NEG8;
+        if (c0 + 8 * q < C) v = *(const f16x8*)(src + ((size_t)b * npx + p) * src_cs + c0 + 8 * q);
+        *(f16x8*)(cur + p * POOL_C + 8 * q) = v;
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int i = threadIdx.x; i < npx * nq; i += 256) {
+            const int p = i / nq, q = i % nq;
+            const int y = p / W, x = p - y * W;
+            f16x8 m = NEG8;
+            for (int dy = -2; dy <= 2; ++dy) {
+                const int yy = y + dy;
+                if ((unsigned)yy >= (unsigned)H) continue;
+                for (int dx = -2; dx <= 2; ++dx) {
+                    const int xx = x + dx;
+                    if ((unsigned)xx >= (unsigned)W) continue;
+                    m = max8(m, *(const f16x8*)(cur + (yy * W + xx) * POOL_C + 8 * q));
+                }
+            }
+            *(f16x8*)(nxt + p * POOL_C + 8 * q) = m;
+            if (c0 + 8 * q < C) *(f16x8*)(dst + ((size_t)b * npx + p) * dst_cs + pass * C + c0 + 8 * q) = m;
+        }
+        __syncthreads();
+        _Float16* t = cur; cur = nxt; nxt = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void sppf_pools_f16_global_kernel(const _Float16* src, int src_cs, _Float16* dst, int dst_cs,
+                                                                    int B, int H, int W, int c8n, int C) {
+    const long total = (long)B * H * W * c8n;
+    const _Float16 NEG = (_Float16)(-__builtin_huge_valf());
+    const f16x8 NEG8 = (f16x8){NEG, NEG, NEG, NEG, NEG, NEG, NEG, NEG};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % c8n);
+        long p = i / c8n;
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H);
+        const int b = (int)(p / H);
+        f16x8 m1 = NEG8, m2 = NEG8, m3 = NEG8;
+        for (int dy = -6; dy <= 6; ++dy) {
+            const int yy = y + dy;
+            if ((unsigned)yy >= (unsigned)H) continue;
+            const int ady = dy < 0 ? -dy : dy;
+            for (int dx = -6; dx <= 6; ++dx) {
+                const int xx = x + dx;
+                if ((unsigned)xx >= (unsigned)W) continue;
+                const int adx = dx < 0 ? -dx : dx;
+                const int r = ady > adx ? ady : adx;
+                const f16x8 v = *(const f16x8*)(src + (((size_t)b * H + yy) * W + xx) * src_cs + 8 * q);
+                m3 = max8(m3, v);
+                if (r <= 4) m2 = max8(m2, v);
+                if (r <= 2) m1 = max8(m1, v);
+            }
+        }
+        _Float16* d = dst + (((size_t)b * H + y) * W + x) * dst_cs + 8 * q;
+        *(f16x8*)d = m1; *(f16x8*)(d + C) = m2; *(f16x8*)(d + 2 * C) = m3;
+    }
+}
+
+const char* launch_sppf_pools_f16(const void* src, int src_cs, void* dst, int dst_cs, int B, int H, int W, int C,
+                                  hipStream_t st) {
+    if (C & 7) return "sppf(f16): channel count must be a multiple of 8";
+    int pc = 0;
+    for (int c = 32; c >= 8; c >>= 1)
+        if ((size_t)2 * H * W * c * 2 <= 48 * 1024) { pc = c; break; }
+    if (!pc) {
+        const int c8n = C / 8;
+        const long total = (long)B * H * W * c8n;
+        const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL(sppf_pools_f16_global_kernel, dim3(grid), dim3(256), 0, st, (const _Float16*)src, src_cs, (_Float16*)dst,
+                           dst_cs, B, H, W, c8n, C);
+    } else {
+        const size_t lds = (size_t)2 * H * W * pc * 2;
+        const unsigned grid = (unsigned)(B * ((C + pc - 1) / pc));
+        hipLaunchKernelGGL(sppf_pools_f16_kernel, dim3(grid), dim3(256), lds, st, (const _Float16*)src, src_cs, (_Float16*)dst, dst_cs,
+                           B, H, W, C, pc);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

@@ -47,12 +47,15 @@ class YOLO:
     """
 
     def __init__(self, model: Union[str, bytes, os.PathLike], task: Optional[str] = None, device: int = 0,
-                 batch_chunk: int = 0, verbose: bool = False):
+                 batch_chunk: int = 0, verbose: bool = False, half: bool = False):
         lib = _lib.lib()
         self._lock = threading.Lock()          # Ultralytics serialises predict() with a per-predictor lock
         self._h = C.c_void_p()
+        self._h_other = C.c_void_p()           # engine of the other precision, created by the first predict(half=...) that needs it
+        self.half = bool(half)                 # precision of the primary engine (predict(half=None) uses it)
         self.device = int(device)
-        opts = _lib.Opts(struct_size=C.sizeof(_lib.Opts), batch_chunk=int(batch_chunk))
+        self._batch_chunk = int(batch_chunk)
+        opts = _lib.Opts(struct_size=C.sizeof(_lib.Opts), batch_chunk=int(batch_chunk), half=int(self.half))
         if isinstance(model, (bytes, bytearray, memoryview)):
             blob = bytes(model)
             self.ckpt_path = None
@@ -68,6 +71,7 @@ class YOLO:
                 with open(path, "rb") as f:
                     blob = f.read()
         self._blob_meta = from_bytes(blob)[2] if blob[:8] == b"MI355YW1" else {}
+        self._blob = blob
         _lib.check(lib.mi355_yolo_create_from_memory(blob, len(blob), self.device, C.byref(opts), C.byref(self._h)))
         info = _lib.ModelInfo()
         _lib.check(lib.mi355_yolo_info(self._h, C.byref(info)))
@@ -88,13 +92,24 @@ class YOLO:
         return cls(build_from_state_dict(name, state_dict, nc=nc), **kw)
 
     def __del__(self):
-        h = getattr(self, "_h", None)
-        if h is not None and h.value:
-            try:
-                _lib.lib().mi355_yolo_destroy(h)
-            except Exception:
-                pass
-            self._h = C.c_void_p()
+        for name in ("_h", "_h_other"):
+            h = getattr(self, name, None)
+            if h is not None and h.value:
+                try:
+                    _lib.lib().mi355_yolo_destroy(h)
+                except Exception:
+                    pass
+                setattr(self, name, C.c_void_p())
+
+    def _handle(self, half: Optional[bool]):
+        """Engine handle for the requested precision (``half=True`` = Ultralytics' predictor argument: fp16 storage)."""
+        if half is None or bool(half) == self.half:
+            return self._h
+        if not self._h_other.value:
+            opts = _lib.Opts(struct_size=C.sizeof(_lib.Opts), batch_chunk=self._batch_chunk, half=int(bool(half)))
+            _lib.check(_lib.lib().mi355_yolo_create_from_memory(self._blob, len(self._blob), self.device, C.byref(opts),
+                                                                C.byref(self._h_other)))
+        return self._h_other
 
     def info(self, detailed: bool = False, verbose: bool = False):
         i = self.info_struct
@@ -125,8 +140,10 @@ class YOLO:
         raise TypeError(f"unsupported source type {type(source).__name__}: pass decoded BGR uint8 frames "
                         f"(frame decode stays on the host, as in the reference's cv2.VideoCapture loop)")
 
-    def _infer_rows(self, batch, conf, iou, classes, max_det, imgsz):
+    def _infer_rows(self, batch, conf, iou, classes, max_det, imgsz, half=None):
         lib = _lib.lib()
+        hnd = self._handle(half)
+        self._last_handle = hnd
         n, h, w = int(batch.shape[0]), int(batch.shape[1]), int(batch.shape[2])
         rows = np.zeros((n, max_det, _lib.DET_WORDS), dtype=np.float32)
         counts = np.zeros(n, dtype=np.int32)
@@ -145,26 +162,26 @@ class YOLO:
                     if batch.device.index != self.device:
                         raise ValueError("frames live on a different GPU than the engine")
                     torch.cuda.current_stream(batch.device).synchronize()   # engine runs on its own stream
-                    _lib.check(lib.mi355_yolo_infer_device(self._h, batch.data_ptr(), n, h, w, conf, iou, cls_arr, ncls,
+                    _lib.check(lib.mi355_yolo_infer_device(hnd, batch.data_ptr(), n, h, w, conf, iou, cls_arr, ncls,
                                                            max_det, imgsz, rows.ctypes.data, max_det, cp))
                     return rows, counts, (h, w)
-            _lib.check(lib.mi355_yolo_infer(self._h, batch.ctypes.data, n, h, w, 0, conf, iou, cls_arr, ncls, max_det,
+            _lib.check(lib.mi355_yolo_infer(hnd, batch.ctypes.data, n, h, w, 0, conf, iou, cls_arr, ncls, max_det,
                                             imgsz, rows.ctypes.data, max_det, cp))
         return rows, counts, (h, w)
 
     def predict(self, source=None, conf: Optional[float] = None, iou: float = 0.7, classes=None, max_det: int = 300,
-                imgsz: int = 640, half: bool = False, verbose: bool = False, stream: bool = False, **kwargs
+                imgsz: int = 640, half: Optional[bool] = None, verbose: bool = False, stream: bool = False, **kwargs
                 ) -> List[Results]:
-        """``model.predict`` / ``model(...)``: ultralytics/engine/model.py:Model.predict."""
-        if half:
-            raise NotImplementedError("half=True: this engine computes in fp32 (the reference's CPU path dtype)")
+        """``model.predict`` / ``model(...)``: ultralytics/engine/model.py:Model.predict.
+        ``half=True`` runs the fp16-storage engine (fp32 accumulate; results differ from fp32 by fp16 rounding);
+        ``None`` = the precision the model was constructed with (fp32 unless ``YOLO(..., half=True)``)."""
         if isinstance(imgsz, (list, tuple)):
             imgsz = int(max(imgsz))
         conf = 0.25 if conf is None else float(conf)
         batch, originals = self._as_batch(source)
-        rows, counts, shape = self._infer_rows(batch, conf, float(iou), classes, int(max_det), int(imgsz))
+        rows, counts, shape = self._infer_rows(batch, conf, float(iou), classes, int(max_det), int(imgsz), half)
         t = _lib.Timing()
-        _lib.lib().mi355_yolo_last_timing(self._h, C.byref(t))
+        _lib.lib().mi355_yolo_last_timing(self._last_handle, C.byref(t))
         per_img_ms = t.total_ms / max(1, int(batch.shape[0]))
         out = []
         for i in range(len(counts)):
@@ -212,25 +229,28 @@ class YOLO:
         return results
 
     # ------------------------------------------------------------------------------------------ test hooks
-    def raw_head(self, source, imgsz: int = 640) -> np.ndarray:
+    def raw_head(self, source, imgsz: int = 640, half: Optional[bool] = None) -> np.ndarray:
         """Pre-NMS head tensor ``[N, 4+nc+nk, A]`` exactly as ``Detect/Pose.forward`` returns it."""
         lib = _lib.lib()
+        hnd = self._handle(half)
         batch, _ = self._as_batch(source)
         if isinstance(batch, torch.Tensor):
             batch = batch.cpu().numpy()
         n, h, w = batch.shape[:3]
         ch, an = C.c_int(), C.c_int()
-        _lib.check(lib.mi355_yolo_raw_head(self._h, None, n, h, w, 0, imgsz, None, C.byref(ch), C.byref(an)))
+        _lib.check(lib.mi355_yolo_raw_head(hnd, None, n, h, w, 0, imgsz, None, C.byref(ch), C.byref(an)))
         out = np.empty((n, ch.value, an.value), dtype=np.float32)
         with self._lock:
-            _lib.check(lib.mi355_yolo_raw_head(self._h, batch.ctypes.data, n, h, w, 0, imgsz, out.ctypes.data,
+            _lib.check(lib.mi355_yolo_raw_head(hnd, batch.ctypes.data, n, h, w, 0, imgsz, out.ctypes.data,
                                                C.byref(ch), C.byref(an)))
         return out
 
     def set_profiling(self, on: bool = True) -> None:
         _lib.check(_lib.lib().mi355_yolo_set_profiling(self._h, int(on)))
+        if self._h_other.value:
+            _lib.check(_lib.lib().mi355_yolo_set_profiling(self._h_other, int(on)))
 
     def last_timing(self) -> dict:
         t = _lib.Timing()
-        _lib.check(_lib.lib().mi355_yolo_last_timing(self._h, C.byref(t)))
+        _lib.check(_lib.lib().mi355_yolo_last_timing(getattr(self, "_last_handle", self._h), C.byref(t)))
         return {k: getattr(t, k) for k, _ in _lib.Timing._fields_}

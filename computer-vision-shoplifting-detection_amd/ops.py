@@ -18,9 +18,12 @@ def _f32(a):
 
 
 def conv2d(x_nhwc: np.ndarray, w_oihw: np.ndarray, bias: np.ndarray, stride: int = 1, silu: bool = True,
-           residual: Optional[np.ndarray] = None, device: int = 0, plan: int = 0, return_n_plans: bool = False):
+           residual: Optional[np.ndarray] = None, device: int = 0, plan: int = 0, return_n_plans: bool = False,
+           half: bool = False, out_f32: bool = False):
     """Fused conv + bias (+SiLU) (+residual): x [N,H,W,Cin] fp32 -> [N,H/s,W/s,Cout].
-    ``plan`` picks one of the engine's candidate launch plans (all must give identical bits)."""
+    ``plan`` picks one of the engine's candidate launch plans (all must give identical bits).
+    ``half``: the half=True kernels -- x, w, residual rounded to fp16, fp32 accumulate, y rounded to fp16 once
+    (``out_f32``: y kept in fp32, as for the head's final convs); values are returned as fp32 either way."""
     x, w, b = _f32(x_nhwc), _f32(w_oihw), _f32(bias)
     n, h, wd, cin = x.shape
     cout, cin2, k, k2 = w.shape
@@ -33,6 +36,11 @@ def conv2d(x_nhwc: np.ndarray, w_oihw: np.ndarray, bias: np.ndarray, stride: int
         r = _f32(residual)
         if r.shape != y.shape:
             raise ValueError("residual must have the output's shape")
+    if half:
+        _lib.check(_lib.lib().mi355_op_conv2d_f16(device, x.ctypes.data, n, h, wd, cin, w.ctypes.data, b.ctypes.data, cout,
+                                                  k, stride, int(silu), r.ctypes.data if r is not None else None,
+                                                  y.ctypes.data, int(out_f32), int(plan), C.byref(npl)))
+        return (y, npl.value) if return_n_plans else y
     _lib.check(_lib.lib().mi355_op_conv2d(device, x.ctypes.data, n, h, wd, cin, w.ctypes.data, b.ctypes.data, cout, k,
                                           stride, int(silu), r.ctypes.data if r is not None else None, y.ctypes.data,
                                           int(plan), C.byref(npl)))

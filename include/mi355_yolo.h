@@ -47,7 +47,10 @@ typedef struct mi355_yolo mi355_yolo;   /* opaque engine handle */
 typedef struct mi355_opts {
     int struct_size;
     int batch_chunk;      /* frames pushed through the net per pass (default 64); larger batches are looped */
-    int reserved[6];
+    int half;             /* 1 = Ultralytics' half=True (engine/predictor.py: model.half(), im.half()): activations and
+                           * weights stored as fp16, fp32 accumulate / bias / SiLU, head logits, decode and NMS in fp32.
+                           * Results then differ from the fp32 path by fp16 rounding (not a bit-exact mode). */
+    int reserved[5];
 } mi355_opts;
 
 /* One post-NMS detection, coordinates in ORIGINAL-image pixels (after scale_boxes / scale_coords).
@@ -136,10 +139,19 @@ int  mi355_yolo_last_timing(const mi355_yolo* h, mi355_timing* t);
 int  mi355_op_conv2d(int device_id, const float* x, int n, int h, int w, int cin, const float* w_oihw,
                      const float* bias, int cout, int k, int stride, int silu, const float* residual, float* y,
                      int plan_index, int* n_plans);
+/* The same operator on the half=True path: x, w and residual are rounded to fp16 (nearest-even) on the way in, the
+ * kernel accumulates in fp32 and rounds y to fp16 once (out_f32 = 1: y is written as fp32, as for the head's final
+ * convs); y is handed back as fp32 values. */
+int  mi355_op_conv2d_f16(int device_id, const float* x, int n, int h, int w, int cin, const float* w_oihw,
+                         const float* bias, int cout, int k, int stride, int silu, const float* residual, float* y,
+                         int out_f32, int plan_index, int* n_plans);
 /* Device-resident timing of one conv launch plan on random data (diagnostics / tuning): average milliseconds over
  * `iters` back-to-back launches of candidate plan `plan_index`; plan_desc (optional) receives a description. */
 int  mi355_bench_conv2d(int device_id, int n, int h, int w, int cin, int cout, int k, int stride, int silu, int residual,
                         int plan_index, int iters, float* avg_ms, int* n_plans, char* plan_desc, int plan_desc_len);
+int  mi355_bench_conv2d_f16(int device_id, int n, int h, int w, int cin, int cout, int k, int stride, int silu,
+                            int residual, int plan_index, int iters, float* avg_ms, int* n_plans, char* plan_desc,
+                            int plan_desc_len);
 /* The u8 stem: letterboxed BGR frames -> (x/255, RGB) -> conv k x k stride s (pad k/2, or 2 for k=6) + bias + SiLU. */
 int  mi355_op_stem(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias,
                    int cout, int k, int stride, float* y);

@@ -70,7 +70,12 @@ def _model_tables(name: str):
 class OracleModel:
     """Functional YOLO forward over an *unfused* Ultralytics-named state dict."""
 
-    def __init__(self, name: str, state_dict: Dict[str, np.ndarray], nc: Optional[int] = None):
+    def __init__(self, name: str, state_dict: Dict[str, np.ndarray], nc: Optional[int] = None, half: bool = False):
+        # half: restates the ENGINE's half=True contract (include/mi355_yolo.h, mi355_opts.half), which is what Ultralytics'
+        # half=True predictor does up to where roundings fall: weights of every conv but the u8 stem rounded to fp16,
+        # every stored activation rounded to fp16 once (after bias + SiLU + residual, all in fp32), the head's final 1x1
+        # convs, decode and NMS in fp32.  Ultralytics itself refuses half on CPU, so this mode has no CPU reference run.
+        self.half = bool(half)
         self.yaml, (self.depth, self.width, self.max_ch), self.pose = _model_tables(name)
         self.nc = nc if nc is not None else (1 if self.pose else 80)
         self.kpt_shape = (17, 3) if self.pose else (0, 0)
@@ -93,19 +98,27 @@ class OracleModel:
             b_conv = torch.zeros(w.shape[0])
             b_bn = b - g.mul(mu).div(torch.sqrt(var + eps))
             bf = torch.mm(w_bn, b_conv.reshape(-1, 1)).reshape(-1) + b_bn
+            if self.half and w.shape[1] != 3:            # the stem reads u8 pixels and keeps fp32 weights
+                wf = wf.half().float()
             self._fused[prefix] = (wf, bf)
         return self._fused[prefix]
 
+    def _store(self, x):
+        """what a stored activation holds: fp32, or fp16-rounded values in half mode"""
+        return x.half().float() if self.half else x
+
     # -- nn/modules/conv.py:Conv.forward_fuse  (act(conv(x)), act = SiLU, pad = autopad(k) unless given)
-    def Conv(self, x, prefix, k, s, p=None):
+    def Conv(self, x, prefix, k, s, p=None, res=None):
         w, b = self._fused_conv(prefix)
         assert w.shape[2] == k, (prefix, w.shape, k)
-        return F.silu(F.conv2d(x, w, b, stride=s, padding=(k // 2 if p is None else p)))
+        y = F.silu(F.conv2d(x, w, b, stride=s, padding=(k // 2 if p is None else p)))
+        if res is not None:
+            y = res + y                      # Bottleneck's `x + self.cv2(self.cv1(x))`
+        return self._store(y)
 
     # -- nn/modules/block.py:Bottleneck
     def Bottleneck(self, x, prefix, shortcut, k=(3, 3)):
-        y = self.Conv(self.Conv(x, prefix + ".cv1", k[0], 1), prefix + ".cv2", k[1], 1)
-        return x + y if shortcut else y
+        return self.Conv(self.Conv(x, prefix + ".cv1", k[0], 1), prefix + ".cv2", k[1], 1, res=x if shortcut else None)
 
     # -- nn/modules/block.py:C2f.forward
     def C2f(self, x, prefix, n, shortcut):
@@ -131,7 +144,8 @@ class OracleModel:
     def _seq3(self, x, prefix):
         """head branch: Conv3 -> Conv3 -> nn.Conv2d 1x1 (with bias, no BN, no act)."""
         x = self.Conv(self.Conv(x, prefix + ".0", 3, 1), prefix + ".1", 3, 1)
-        return F.conv2d(x, self.sd[prefix + ".2.weight"], self.sd[prefix + ".2.bias"])
+        w = self.sd[prefix + ".2.weight"]
+        return F.conv2d(x, w.half().float() if self.half else w, self.sd[prefix + ".2.bias"])
 
     # -- nn/modules/head.py:Detect.forward/_inference, Pose.forward/kpts_decode; utils/tal.py
     def Head(self, feats: List[torch.Tensor], prefix: str):
