@@ -31,6 +31,10 @@ void pack_conv_weights(const float* w_oihw, int cout, int cin, int k, float* out
 // fp16 variant: ceil(cout/16) * k*k * ceil(cin/32) * 512 halfs, [cout_tile][tap][cin_block32][lane(64)][8], RNE from fp32
 size_t packed_weight_halfs(int cout, int cin, int k);
 void pack_conv_weights_f16(const float* w_oihw, int cout, int cin, int k, uint16_t* out_bits);
+// fp16 kernels, Cout % 32 == 0: the rows of each PAIR of 16-cout MFMA tiles are interleaved (tile 2j row 4g+i = cout
+// 32j+8g+i, tile 2j+1 row 4g+i = cout 32j+8g+4+i), so that a lane's 4+4 outputs are 8 consecutive couts = one 16-byte fp16
+// store.  A pure relabelling of weight rows done at pack time; the packer and the kernels both ask this function.
+__host__ __device__ inline bool conv_f16_pairs(int cout) { return (cout % 32) == 0; }
 void floats_to_halfs(const float* in, uint16_t* out_bits, size_t n);     // round-to-nearest-even
 void halfs_to_floats(const uint16_t* in_bits, float* out, size_t n);
 const void* pick_conv_kernel_f16(int ks, int stride, int CT, int WP, int version, int stream_pt);
@@ -51,7 +55,7 @@ struct ConvKArgs {
 };
 // A planned launch: kernel instance, grid, LDS bytes and kernel arguments.  Planning (tile / wave-arrangement
 // search) is done once per (op, shape) by the engine; run_conv only enqueues.
-struct ConvLaunch { const void* fn; unsigned grid_x, grid_y; size_t lds; ConvKArgs a; int CT, WP; double flops; int threads; int version; };
+struct ConvLaunch { const void* fn; unsigned grid_x, grid_y; size_t lds; ConvKArgs a; int CT, WP; double flops; int threads; int version; int PT; };
 const char* plan_conv(const ConvArgs& c, ConvLaunch* out);
 const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out);   // best static guess first
 const char* run_conv(const ConvLaunch& l, hipStream_t st);

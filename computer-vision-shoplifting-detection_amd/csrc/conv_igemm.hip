@@ -546,7 +546,7 @@ void pack_conv_weights(const float* w, int cout, int cin, int k, float* out) {
 
 namespace {
 
-struct Plan { int CT, WP, TW, TH, ck; size_t lds; double cost; int version; int buf_floats; };
+struct Plan { int CT, WP, TW, TH, ck; size_t lds; double cost; int version; int buf_floats; int PT; };   // PT 0 = default (4, or 3 with CT 5)
 
 typedef void (*KernelFn)(ConvKArgs);
 
@@ -614,10 +614,14 @@ std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, i
     static const int min_wc = env_int("MI355_MIN_WC", 1);
     std::vector<Plan> out;
     const int cin16 = round_up(cin, 16);
+    // fp16 only: wave tiles of 8 pixel tiles (128 pixels x CT*16 couts) halve the weight bytes fetched per MFMA -- the f16
+    // MFMA retires a 1-KiB fragment pair in 16 cycles, so these kernels are bound by L1/L2 fragment traffic, not by the pipe
+    for (int PTsel = 0; PTsel <= (half ? 8 : 0); PTsel += 8)
     for (int WC = 1; WC <= 4; WC *= 2)
         for (int CT = 1; CT <= 5; ++CT) {
             if (CT > max_ct || WC < min_wc) continue;
-            const int WP = 4 / WC, PT = (CT == 5 ? 3 : 4), P = WP * PT * 16;
+            if (PTsel == 8 && CT > 4) continue;
+            const int WP = 4 / WC, PT = PTsel ? PTsel : (CT == 5 ? 3 : 4), P = WP * PT * 16;
             const int cover = CT * WC, nblk = (n_ctiles + cover - 1) / cover;
             if (cover >= 2 * n_ctiles && cover > CT) continue;          // more than half of the cout tiles would be padding
             const double waste_c = (double)nblk * cover / n_ctiles;
@@ -636,7 +640,7 @@ std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, i
                     const int stages = (cin16 + ck - 1) / ck;
                     double cost = infl * (1.0 + 0.03 * halo * nblk) * (1.0 + 0.04 * (stages - 1)) * (1.0 + 0.04 * (CT - 1))
                                   + (lds > LDS_SOFT ? 0.15 : 0.0);
-                    if (cost < best.cost) best = Plan{CT, WP, TW, TH, ck, lds, cost, 1, 0};
+                    if (cost < best.cost) best = Plan{CT, WP, TW, TH, ck, lds, cost, 1, 0, PTsel};
                 }
                 if (best.cost < 1e30) {
                     out.push_back(best);
@@ -662,7 +666,7 @@ std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, i
                 const int CT = cts[ci], PT = pts[pi];
                 if (CT > n_ctiles && CT != 1) continue;
                 const int nblk = (n_ctiles + CT - 1) / CT;
-                Plan p3{CT, 4, PT * 64, 1, 16, 0, 0.0, 3, PT};
+                Plan p3{CT, 4, PT * 64, 1, 16, 0, 0.0, 3, PT, 0};
                 p3.cost = (double)nblk * CT / n_ctiles * (1.0 + 0.05 * nblk) * 0.9;
                 out.push_back(p3);
             }
@@ -679,7 +683,9 @@ static const char* check_args(const ConvArgs& c) {
     if (c.dtype == 1) {     // fp16 storage: 16-byte source vectors = 8 halfs, 8-byte (or fp32 16-byte) destination vectors
         if ((c.src_cs & 7) || (c.dst_cs & 3) || (c.res && (c.res_cs & 3))) return "conv(f16): channel strides must be multiples of 8 (src) / 4 (dst)";
         if (((uintptr_t)c.src | (uintptr_t)c.wpk | (uintptr_t)c.bias) & 15) return "conv(f16): src / weight / bias pointers must be 16-byte aligned";
-        if (((uintptr_t)c.dst | (uintptr_t)c.res) & (c.out_f32 ? 15 : 7)) return "conv(f16): dst / residual pointers are misaligned";
+        const bool wide = !c.out_f32 && conv_f16_pairs(c.Cout);          // 16-byte fp16 stores of 8 consecutive couts
+        if (((uintptr_t)c.dst | (uintptr_t)c.res) & ((c.out_f32 || wide) ? 15 : 7)) return "conv(f16): dst / residual pointers are misaligned";
+        if (wide && ((c.dst_cs & 7) || (c.res && (c.res_cs & 7)))) return "conv(f16): dst / residual strides must be multiples of 8";
         if (!c.zeros) return "conv: zero page missing";
         return nullptr;
     }
@@ -705,7 +711,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     } else {
         a.Hin = c.Hin; a.Win = c.Win; a.Hout = c.Hout; a.Wout = c.Wout;
     }
-    KernelFn fn = half ? (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.buf_floats)
+    KernelFn fn = half ? (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.version == 3 ? p.buf_floats : p.PT)
                        : (p.version == 3 ? pick_stream(p.CT, p.buf_floats) : pick_kernel(c.k, c.stride, p.CT, p.WP, p.version));
     if (!fn) return "conv: no kernel instance";
     a.zeros = c.zeros; a.lds_buf_floats = p.buf_floats;
@@ -730,7 +736,8 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     out->grid_y = (unsigned)((a.n_ctiles + p.CT * WC - 1) / (p.CT * WC));
     out->lds = p.lds;
     out->a = a;
-    out->CT = p.CT; out->WP = p.WP; out->version = p.version; out->threads = p.version == 2 ? 320 : 256;
+    out->CT = p.CT; out->WP = p.WP; out->version = p.version;
+    out->PT = p.version == 3 ? p.buf_floats : (p.PT ? p.PT : (p.CT == 5 ? 3 : 4)); out->threads = p.version == 2 ? 320 : 256;
     if (p.version == 3) {          // streaming 1x1: block = 4 waves x PT pixel tiles, grid.y over cout blocks of CT tiles
         const int PT = p.buf_floats;
         out->grid_x = (unsigned)((a.Wout + 4 * PT * 16 - 1) / (4 * PT * 16));

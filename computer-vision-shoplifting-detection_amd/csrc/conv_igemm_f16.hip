@@ -21,10 +21,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+// first cout of the 4 consecutive couts lane group g holds for cout tile `ctile` (see conv_f16_pairs)
+__device__ __forceinline__ int tile_cout0(int ctile, int g, bool pairs) {
+    return pairs ? ((ctile >> 1) * 32 + 8 * g + 4 * (ctile & 1)) : (ctile * 16 + 4 * g);
+}
+
 // bias + SiLU (+ residual) in fp32, one rounding to fp16 (or a plain fp32 store for the head outputs)
 template <int PT, int CT>
 __device__ __forceinline__ void store_tiles_f16(const ConvKArgs& a, f32x4 (&acc)[CT][PT], const f32x4 (&bias4)[CT], int lane,
                                                 int ct0, const size_t (&po)[PT], const bool (&ok)[PT]) {
+    const bool pairs = conv_f16_pairs(a.Cout);
+    const int g = lane >> 4;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -33,11 +40,32 @@ __device__ __forceinline__ void store_tiles_f16(const ConvKArgs& a, f32x4 (&acc)
             if (a.act) { v[0] = det_silu(v[0]); v[1] = det_silu(v[1]); v[2] = det_silu(v[2]); v[3] = det_silu(v[3]); }
             acc[ct][pt] = v;
         }
+    if (!a.out_f32 && pairs && (CT % 2 == 0)) {
+        // ct0 is even (a multiple of CT): tiles (ct, ct+1) are a pair -> 8 consecutive couts per lane, one 16-byte store
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ct += 2) {
+                const int c = tile_cout0(ct0 + ct, g, true);
+                if (!ok[pt] || c >= a.Cout) continue;
+                f32x4 v0 = acc[ct][pt], v1 = acc[ct + 1][pt];
+                if (a.res) {
+                    const f16x8 rv = *(const f16x8*)((const _Float16*)a.res + po[pt] * a.res_cs + c);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v0[i] += (float)rv[i]; v1[i] += (float)rv[4 + i]; }
+                }
+                f16x8 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { o[i] = (_Float16)v0[i]; o[4 + i] = (_Float16)v1[i]; }
+                *(f16x8*)((_Float16*)a.dst + po[pt] * a.dst_cs + c) = o;
+            }
+        return;
+    }
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            const int c = (ct0 + ct) * 16 + (lane >> 4) * 4;
+            const int c = tile_cout0(ct0 + ct, g, pairs);
             if (!ok[pt] || c >= a.Cout) continue;
             f32x4 v = acc[ct][pt];
             if (a.out_f32) {
@@ -107,7 +135,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(ConvKArgs a) {
     for (int ct = 0; ct < CT; ++ct) {
         const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);   // padded cout tiles re-read the last one
         wbase[ct] = (const _Float16*)a.wpk + (size_t)ctile * TAPS * a.cib * 512 + lane * 8;
-        bias4[ct] = *(const f32x4*)(a.bias + ctile * 16 + (lane >> 4) * 4);
+        bias4[ct] = *(const f32x4*)(a.bias + tile_cout0(ctile, lane >> 4, conv_f16_pairs(a.Cout)));
     }
     const int ck8m = (a.ck >> 3) - 1;
     const int total_v = a.npix_in << a.ck4_shift;          // 16-byte slots of one staged chunk
@@ -221,7 +249,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_f16(ConvKArgs a) {
     for (int ct = 0; ct < CT; ++ct) {
         const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
         wbase[ct] = (const _Float16*)a.wpk + (size_t)ctile * a.cib * 512 + lane * 8;
-        bias4[ct] = *(const f32x4*)(a.bias + ctile * 16 + g * 4);
+        bias4[ct] = *(const f32x4*)(a.bias + tile_cout0(ctile, g, conv_f16_pairs(a.Cout)));
     }
     f32x4 acc[CT][PT];
 #pragma unroll
@@ -276,13 +304,15 @@ size_t packed_weight_halfs(int cout, int cin, int k) {
 void pack_conv_weights_f16(const float* w, int cout, int cin, int k, uint16_t* out_bits) {
     _Float16* out = (_Float16*)out_bits;
     const int nct = (cout + 15) / 16, cib = (cin + 31) / 32, taps = k * k;
+    const bool pairs = conv_f16_pairs(cout);
     for (int ct = 0; ct < nct; ++ct)
         for (int tap = 0; tap < taps; ++tap)
             for (int cb = 0; cb < cib; ++cb) {
                 _Float16* o = out + ((size_t)(ct * taps + tap) * cib + cb) * 512;
                 for (int lane = 0; lane < 64; ++lane)
                     for (int s = 0; s < 8; ++s) {
-                        const int co = ct * 16 + (lane & 15);
+                        const int r = lane & 15;         // MFMA row of this cout tile
+                        const int co = pairs ? ((ct >> 1) * 32 + 8 * (r >> 2) + 4 * (ct & 1) + (r & 3)) : (ct * 16 + r);
                         const int ci = cb * 32 + 8 * (lane >> 4) + s;
                         o[lane * 8 + s] = (co < cout && ci < cin) ? (_Float16)w[((size_t)co * cin + ci) * taps + tap] : (_Float16)0.f;
                     }
@@ -304,7 +334,15 @@ namespace {
 typedef void (*KernelFn)(ConvKArgs);
 
 template <int KS, int STRIDE>
-KernelFn pick_ct_wp_h(int CT, int WP) {
+KernelFn pick_ct_wp_h(int CT, int WP, int PT) {
+    if (PT == 8) {
+#define MI355_CASE8(ct, wp) if (CT == ct && WP == wp) return &conv_igemm_f16<KS, STRIDE, 8, ct, wp>;
+        MI355_CASE8(1, 4) MI355_CASE8(2, 4) MI355_CASE8(3, 4) MI355_CASE8(4, 4)
+        MI355_CASE8(1, 2) MI355_CASE8(2, 2) MI355_CASE8(3, 2) MI355_CASE8(4, 2)
+        MI355_CASE8(1, 1) MI355_CASE8(2, 1) MI355_CASE8(3, 1) MI355_CASE8(4, 1)
+#undef MI355_CASE8
+        return nullptr;
+    }
 #define MI355_CASE(ct, wp) if (CT == ct && WP == wp) return &conv_igemm_f16<KS, STRIDE, (ct == 5 ? 3 : 4), ct, wp>;
     MI355_CASE(1, 4) MI355_CASE(2, 4) MI355_CASE(3, 4) MI355_CASE(4, 4) MI355_CASE(5, 4)
     MI355_CASE(1, 2) MI355_CASE(2, 2) MI355_CASE(3, 2) MI355_CASE(4, 2) MI355_CASE(5, 2)
@@ -315,7 +353,7 @@ KernelFn pick_ct_wp_h(int CT, int WP) {
 
 }  // namespace
 
-const void* pick_conv_kernel_f16(int ks, int stride, int CT, int WP, int version, int stream_pt) {
+const void* pick_conv_kernel_f16(int ks, int stride, int CT, int WP, int version, int stream_pt /* v3: PT; v1: 0 or 8 */) {
     if (version == 3) {
         if (CT == 1 && stream_pt == 2) return (const void*)&conv1x1_stream_f16<2, 1>;
         if (CT == 1 && stream_pt == 4) return (const void*)&conv1x1_stream_f16<4, 1>;
@@ -326,9 +364,9 @@ const void* pick_conv_kernel_f16(int ks, int stride, int CT, int WP, int version
         return nullptr;
     }
     if (version != 1) return nullptr;
-    if (ks == 1 && stride == 1) return (const void*)pick_ct_wp_h<1, 1>(CT, WP);
-    if (ks == 3 && stride == 1) return (const void*)pick_ct_wp_h<3, 1>(CT, WP);
-    if (ks == 3 && stride == 2) return (const void*)pick_ct_wp_h<3, 2>(CT, WP);
+    if (ks == 1 && stride == 1) return (const void*)pick_ct_wp_h<1, 1>(CT, WP, stream_pt);
+    if (ks == 3 && stride == 1) return (const void*)pick_ct_wp_h<3, 1>(CT, WP, stream_pt);
+    if (ks == 3 && stride == 2) return (const void*)pick_ct_wp_h<3, 2>(CT, WP, stream_pt);
     return nullptr;
 }
 

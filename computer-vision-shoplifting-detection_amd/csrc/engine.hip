@@ -325,13 +325,13 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                 }
                 if (ms < best_ms) { best_ms = ms; h->plans[i] = cands[k]; chosen[i] = (int)k; }
                 if (tune_log)
-                    fprintf(stderr, "[tune] %-22s %4u->%-4u k%u s%u @%dx%d  v%d CT%d WP%d tile %dx%d ck%d lds %zu grid %ux%u : %.1f us  %.1f TFLOP/s\n",
-                            c.name, c.cin, c.cout, c.k, c.s, a.Hout, a.Wout, cands[k].version, cands[k].CT, cands[k].WP, cands[k].a.TW,
+                    fprintf(stderr, "[tune] %-22s %4u->%-4u k%u s%u @%dx%d  v%d CT%d PT%d WP%d tile %dx%d ck%d lds %zu grid %ux%u : %.1f us  %.1f TFLOP/s\n",
+                            c.name, c.cin, c.cout, c.k, c.s, a.Hout, a.Wout, cands[k].version, cands[k].CT, cands[k].PT, cands[k].WP, cands[k].a.TW,
                             cands[k].a.TH, cands[k].a.ck, cands[k].lds, cands[k].grid_x, cands[k].grid_y, ms * 1e3,
                             cands[k].flops / (ms * 1e-3) / 1e12);
             }
-            if (tune_log) fprintf(stderr, "[tune] -> v%d CT%d WP%d tile %dx%d ck%d : %.1f us\n", h->plans[i].version, h->plans[i].CT,
-                                  h->plans[i].WP, h->plans[i].a.TW, h->plans[i].a.TH, h->plans[i].a.ck, best_ms * 1e3);
+            if (tune_log) fprintf(stderr, "[tune] -> v%d CT%d PT%d WP%d tile %dx%d ck%d : %.1f us\n", h->plans[i].version, h->plans[i].CT,
+                                  h->plans[i].PT, h->plans[i].WP, h->plans[i].a.TW, h->plans[i].a.TH, h->plans[i].a.ck, best_ms * 1e3);
         }
     }
     if (!cached && h->autotune) h->tuned.push_back({shape_key, chosen});
@@ -655,6 +655,7 @@ static int create_impl(const uint8_t* blob, size_t nbytes, int device_id, const 
     h->device = device_id;
     if (opts && opts->struct_size >= (int)sizeof(mi355_opts) && opts->batch_chunk > 0) h->chunk = opts->batch_chunk;
     if (opts && opts->struct_size >= (int)sizeof(mi355_opts)) h->half = opts->half != 0;
+    if (h->half) h->autotune = 28;     // the fp16 plan space also spans the pixel tiles per wave
     if (const char* e = getenv("MI355_AUTOTUNE")) h->autotune = std::max(0, atoi(e));
     if (const char* e = getenv("MI355_GRAPH")) h->use_graph = atoi(e);
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -939,7 +940,7 @@ static int bench_conv2d_impl(int device_id, int n, int h, int w, int cin, int co
     if (n_plans) *n_plans = (int)cands.size();
     const ConvLaunch& l = cands[(size_t)(plan_index < 0 ? 0 : plan_index) % cands.size()];
     if (plan_desc && plan_desc_len > 0)
-        snprintf(plan_desc, plan_desc_len, "v%d CT%d WP%d tile %dx%d ck%d lds %zu grid %ux%u", l.version, l.CT, l.WP, l.a.TW, l.a.TH, l.a.ck,
+        snprintf(plan_desc, plan_desc_len, "v%d CT%d PT%d WP%d tile %dx%d ck%d lds %zu grid %ux%u", l.version, l.CT, l.PT, l.WP, l.a.TW, l.a.TH, l.a.ck,
                  l.lds, l.grid_x, l.grid_y);
     if (getenv("MI355_STAMPS") && l.version == 1 && !half) {
         // diagnostic: one stamped launch; prints the mean per-wave phase durations (shader cycles)

@@ -2,6 +2,7 @@
 // and the letterbox resize/pad.  All NHWC, 16-byte accesses per lane wherever the layout allows.
 #include "common.h"
 #include "detmath.h"
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -101,13 +102,183 @@ __global__ __launch_bounds__(256) void stem_conv_u8(StemArgs a) {
     }
 }
 
+// The same layer on the fp32 matrix pipe: an implicit GEMM with K = KS*KS*3 (27 or 108, padded to a multiple of 4) whose
+// B operand is gathered from the LDS input tile through a per-lane offset table (im2col on the fly, one ds_read_b32 per
+// MFMA operand).  k runs (kh, kw, byte channel B,G,R) ascending and v_mfma_f32_16x16x4_f32 chains its 4 k-values in
+// order, so the sum is the SAME fma chain as stem_conv_u8 / the oracle's det_stem -- bit for bit -- at 4-5x the rate
+// of the vector-ALU kernel (which peaked at ~15 TFLOP/s, below both the HBM and the matrix roof of this layer).
+// Block = 256 threads = 4 waves, output tile 16 x 16: wave w owns pixel rows 4w..4w+3 (4 MFMA pixel tiles) x CT cout tiles.
+// Input bytes are fetched as aligned dwords (4 pixels' worth of bytes per load) instead of one byte per lane.
+template <int KS, int CT>
+__global__ __launch_bounds__(256) void stem_mfma_u8(StemArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sl[];
+    constexpr int K = KS * KS * 3, NS = (K + 3) / 4, PT = 4;
+    const int TIN = (STEM_TO - 1) * a.stride + KS;
+    const int trow = TIN * 3;                                   // floats (= source bytes) per tile row
+    float* lut = sl;
+    float* tin = sl + 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    lut[tid] = a.lut[tid];
+    const int tiles_x = (a.Wout + STEM_TO - 1) / STEM_TO, tiles_y = (a.Hout + STEM_TO - 1) / STEM_TO;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int oy0 = ty * STEM_TO, ox0 = tx * STEM_TO;
+    const int iy0 = oy0 * a.stride - a.pad, ix0 = ox0 * a.stride - a.pad;
+    const uint8_t* img = a.img + (size_t)b * a.H * a.W * 3;
+    // A operand: lane (row r = cout, k-group g) holds W[cout][k = 4s + g] for every step s (zero beyond K / Cout);
+    // byte channel cb (0=B,1=G,2=R) feeds model channel 2-cb (im[..., ::-1])
+    float wa[NS][CT];
+    int koff[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int k = 4 * s + g;
+        const int tap = k / 3, cb = k - tap * 3;
+        const int kh = tap / KS, kw = tap - kh * KS;
+        koff[s] = k < K ? (kh * TIN + kw) * 3 + cb : 0;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int co = ct * 16 + (lane & 15);
+            wa[s][ct] = (k < K && co < a.Cout) ? a.w[((size_t)co * 3 + (2 - cb)) * (KS * KS) + tap] : 0.f;
+        }
+    }
+    __syncthreads();                                            // lut visible
+    // ---- input tile: u8 -> float through the table, 0 outside the image (fma(0, w, acc) == acc: same as skipping) ----
+    const int nd = (trow + 6) >> 2;                             // aligned dwords that cover a tile row at any alignment
+    const int n_items = TIN * nd;
+    // batches of 4 dwords per thread, all loads issued before the first table lookup (one memory latency per batch)
+    for (int base_item = 0; base_item < n_items; base_item += 4 * 256) {
+        unsigned bytes[4];
+        long long dd[4], tlo[4], rlo[4];
+        int riy[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int item = base_item + u * 256 + tid;
+            const int iy = item / nd, j = item - iy * nd;
+            const int gy = iy0 + iy;
+            const bool rowin = item < n_items && (unsigned)gy < (unsigned)a.H;
+            const uint8_t* rowp = img + (size_t)(rowin ? gy : 0) * a.W * 3;
+            const long long row_lo = (long long)(uintptr_t)rowp, row_hi = row_lo + (long long)a.W * 3;
+            const long long tile_lo = row_lo + (long long)ix0 * 3;
+            const long long d = (tile_lo & ~3ll) + 4 * j;      // absolute address of this aligned dword
+            unsigned v = 0;
+            if (rowin) {
+                if (d >= row_lo && d + 4 <= row_hi) {
+                    v = *(const unsigned*)(uintptr_t)d;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (d + q >= row_lo && d + q < row_hi) v |= (unsigned)(*(const uint8_t*)(uintptr_t)(d + q)) << (8 * q);
+                }
+            }
+            bytes[u] = v; dd[u] = d; tlo[u] = tile_lo; riy[u] = item < n_items ? iy : -1;
+            rlo[u] = rowin ? row_lo : (1ll << 62);             // rows outside the image: no byte is "in the image"
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (riy[u] < 0) continue;
+            const long long row_hi = rlo[u] + (long long)a.W * 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long long ab = dd[u] + q, rel = ab - tlo[u];
+                if (rel >= 0 && rel < trow) {
+                    const bool inimg = ab >= rlo[u] && ab < row_hi;
+                    tin[riy[u] * trow + (int)rel] = inimg ? lut[(bytes[u] >> (8 * q)) & 255u] : 0.f;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    int base[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int ly = wave * PT + pt, lx = lane & 15;
+        base[pt] = ((ly * a.stride) * TIN + lx * a.stride) * 3;
+    }
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float xb[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) xb[pt] = tin[base[pt] + koff[s]];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+                acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][ct], xb[pt], acc[ct][pt], 0, 0, 0);
+    }
+    // ---- epilogue: lane holds couts 16ct + 4g .. +3 of pixel (row 4*wave + pt, column lane & 15) ----
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int oy = oy0 + wave * PT + pt, ox = ox0 + (lane & 15);
+        if (oy >= a.Hout || ox >= a.Wout) continue;
+        const size_t po = ((size_t)b * a.Hout + oy) * a.Wout + ox;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = ct * 16 + 4 * g;
+            if (c >= a.Cout) continue;
+            const f32x4 v = acc[ct][pt];
+            if (a.out_half) {
+                _Float16* dh = (_Float16*)a.dst + po * a.dst_cs + c;
+                if (c + 3 < a.Cout) {
+                    f16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)silu_m(v[j] + a.bias[c + j]);
+                    *(f16x4*)dh = o;
+                } else {
+                    for (int j = 0; j < 4 && c + j < a.Cout; ++j) dh[j] = (_Float16)silu_m(v[j] + a.bias[c + j]);
+                }
+            } else {
+                float* d = a.dst + po * a.dst_cs + c;
+                if (c + 3 < a.Cout) {
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = silu_m(v[j] + a.bias[c + j]);
+                    *(f32x4*)d = o;
+                } else {
+                    for (int j = 0; j < 4 && c + j < a.Cout; ++j) d[j] = silu_m(v[j] + a.bias[c + j]);
+                }
+            }
+        }
+    }
+}
+
+template <int KS>
+static bool launch_stem_mfma(const StemArgs& a, unsigned grid, hipStream_t st) {
+    const int tin = (STEM_TO - 1) * a.stride + KS;
+    const size_t lds = (256 + (size_t)tin * tin * 3) * sizeof(float);
+    if (lds > 64 * 1024) return false;
+    const int ct = (a.Cout + 15) / 16;
+    switch (ct) {
+        case 1: hipLaunchKernelGGL((stem_mfma_u8<KS, 1>), dim3(grid), dim3(256), lds, st, a); return true;
+        case 2: hipLaunchKernelGGL((stem_mfma_u8<KS, 2>), dim3(grid), dim3(256), lds, st, a); return true;
+        case 3: hipLaunchKernelGGL((stem_mfma_u8<KS, 3>), dim3(grid), dim3(256), lds, st, a); return true;
+        case 4: hipLaunchKernelGGL((stem_mfma_u8<KS, 4>), dim3(grid), dim3(256), lds, st, a); return true;
+        case 5: hipLaunchKernelGGL((stem_mfma_u8<KS, 5>), dim3(grid), dim3(256), lds, st, a); return true;
+        default: return false;
+    }
+}
+
 const char* launch_stem(const StemArgs& a, hipStream_t st) {
     if (a.k != 3 && a.k != 6) return "stem: only 3x3 and 6x6 stems are supported";
+    const unsigned grid = (unsigned)((long)a.B * ((a.Wout + STEM_TO - 1) / STEM_TO) * ((a.Hout + STEM_TO - 1) / STEM_TO));
+    static const bool use_mfma = []() { const char* e = getenv("MI355_STEM_MFMA"); return e ? atoi(e) != 0 : true; }();
+    if (use_mfma && (a.dst_cs & 3) == 0) {
+        const bool ok = a.k == 3 ? launch_stem_mfma<3>(a, grid, st) : launch_stem_mfma<6>(a, grid, st);
+        if (ok) {
+            hipError_t e = hipGetLastError();
+            return e == hipSuccess ? nullptr : hipGetErrorString(e);
+        }
+    }
     const int cq = (a.Cout + 3) / 4;
     const int tin = (STEM_TO - 1) * a.stride + a.k;
     const size_t lds = ((size_t)a.k * a.k * 3 * cq * 4 + 256 + (size_t)tin * tin * 3) * sizeof(float);
     if (lds > 64 * 1024) return "stem: tile does not fit in LDS";
-    const unsigned grid = (unsigned)((long)a.B * ((a.Wout + STEM_TO - 1) / STEM_TO) * ((a.Hout + STEM_TO - 1) / STEM_TO));
     if (a.k == 3) hipLaunchKernelGGL(stem_conv_u8<3>, dim3(grid), dim3(256), lds, st, a);
     else          hipLaunchKernelGGL(stem_conv_u8<6>, dim3(grid), dim3(256), lds, st, a);
     hipError_t e = hipGetLastError();

@@ -12,12 +12,13 @@ path = sys.argv[1]
 model = sys.argv[2] if len(sys.argv) > 2 else "yolov8n"
 chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 size = int(sys.argv[4]) if len(sys.argv) > 4 else 640
+es = float(sys.argv[5]) if len(sys.argv) > 5 else 4.0      # activation element size: 4 = fp32, 2 = the half=True engine
 prog = build_program(*parse_model_name(model))
 rows = [r for r in csv.DictReader(open(path)) if "mi355::" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 seq = []
 for op in prog.ops:
-    seq.append({OP_STEM: "stem_conv_u8", OP_CONV: "conv", OP_UPSAMPLE: "upsample2x", OP_SPPF_POOL: "sppf_pools"}[op.type])
+    seq.append({OP_STEM: "stem_", OP_CONV: "conv", OP_UPSAMPLE: "upsample2x", OP_SPPF_POOL: "sppf_pools"}[op.type])
 seq += ["decode_kernel", "nms_sort_kernel", "nms_greedy_kernel"]
 # split the trace into passes
 passes, i = [], 0
@@ -39,7 +40,7 @@ for j, name in enumerate(seq):
         op = prog.ops[j]; c = prog.convs[op.conv]
         hw = (size // c.stride_div) ** 2
         fl = 2.0 * c.cout * c.cin * c.k * c.k * hw * chunk
-        by = 4.0 * chunk * (c.cin * hw * c.s * c.s + c.cout * hw)
+        by = es * chunk * (c.cin * hw * c.s * c.s + c.cout * hw)
         print(f"{c.name:26s} {tmpl:24s} {f'{c.cin}->{c.cout} k{c.k}s{c.s} @{size//c.stride_div}':30s} "
               f"{r['Grid_Size_X'] + 'x' + r['Grid_Size_Y']:>12s} {r['LDS_Block_Size']:>6s} {int(r['VGPR_Count'])+int(r['Accum_VGPR_Count']):>5d} {us:8.1f} {fl / us / 1e6:8.2f} {by / us / 1e3:7.0f}")
     else:

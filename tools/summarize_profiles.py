@@ -1,33 +1,55 @@
-"""Turn the raw rocprofv3 output of tools/collect_profiles.sh (under gpurun_out/) into the committed profiles/ files."""
+"""Turn the raw rocprofv3 output of tools/collect_profiles.sh (under gpurun_out/) into the committed profiles/ files.
+
+usage: summarize_profiles.py TAG BATCH [MODEL [SIZE [half]]]   (defaults: r01_v3 256 yolov8n 640)"""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_v3"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+model = sys.argv[3] if len(sys.argv) > 3 else "yolov8n"
+size = int(sys.argv[4]) if len(sys.argv) > 4 else 640
+half = len(sys.argv) > 5 and sys.argv[5] == "half"
+es = 2 if half else 4
 g = lambda pat: glob.glob(os.path.join(ROOT, "gpurun_out", pat))[0]
 shutil.copy(g(f"{tag}_trace/*/*kernel_stats.csv"), os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
 with open(os.path.join(ROOT, "profiles", f"{tag}_bench_under_rocprof.json"), "w") as f:
     f.write([l for l in open(os.path.join(ROOT, "gpurun_out", f"{tag}_trace.log")) if l.startswith('{"metric')][-1])
-rep = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "layer_report.py"), g(f"{tag}_trace/*/*kernel_trace.csv"), "yolov8n", str(batch)],
-                     capture_output=True, text=True).stdout
-open(os.path.join(ROOT, "profiles", f"{tag}_layer_report.txt"), "w").write(rep)
-print(rep[-400:])
+rep = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "layer_report.py"), g(f"{tag}_trace/*/*kernel_trace.csv"), model, str(batch),
+                      str(size), str(es)], capture_output=True, text=True)
+open(os.path.join(ROOT, "profiles", f"{tag}_layer_report.txt"), "w").write(rep.stdout)
+print(rep.stdout[-600:], rep.stderr[-2000:])
 
-def conv_sum(pat, counter, passes=6, per_pass=62):
+sys.path.insert(0, ROOT)
+from cvsd_amd.graph import build_program, parse_model_name
+pg = build_program(*parse_model_name(model))
+n_conv = sum(1 for c in pg.convs if c.cin != 3)
+is_conv = lambda name: "conv_igemm" in name or "conv1x1_stream" in name
+
+
+def conv_sum(pat, counter, passes=6):
     rows = sorted((int(r["Dispatch_Id"]), float(r["Counter_Value"])) for r in csv.DictReader(open(g(pat)))
-                  if r["Counter_Name"] == counter and ("conv_igemm" in r["Kernel_Name"] or "conv1x1_stream" in r["Kernel_Name"]))
-    return sum(v for _, v in rows[-passes * per_pass:]) / passes
+                  if r["Counter_Name"] == counter and is_conv(r["Kernel_Name"]))
+    return sum(v for _, v in rows[-passes * n_conv:]) / passes
+
+
 f = conv_sum(f"{tag}_fetch/*/*counter_collection.csv", "FETCH_SIZE")
 w = conv_sum(f"{tag}_write/*/*counter_collection.csv", "WRITE_SIZE")
-sys.path.insert(0, ROOT)
-from cvsd_amd.graph import build_program
-pg = build_program("v8", "n", "detect")
-alg_in = sum(4 * c.cin * (640 // c.stride_div * c.s) ** 2 for c in pg.convs if c.cin != 3) * batch
-alg_out = sum(4 * c.cout * (640 // c.stride_div) ** 2 for c in pg.convs if c.cin != 3) * batch
+sc = (size / 640.0) ** 2
+alg_in = sum(es * c.cin * (640 // c.stride_div * c.s) ** 2 for c in pg.convs if c.cin != 3) * batch * sc
+alg_out = sum(es * c.cout * (640 // c.stride_div) ** 2 for c in pg.convs if c.cin != 3) * batch * sc
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `bench.py --steps 2 --warmup 1`; conv dispatches "
                  "of the 6 real passes only (the engine's one-off autotune launches are excluded)",
+       "workload": f"{model} {size}x{size} batch {batch}" + (" half=True" if half else ""),
        "units": "KiB; FETCH doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests as 64 B) -- uncalibrated for 64-B-segment reads",
-       "frames_per_step": batch, "conv_launches_per_step": 62, "fetch_kib_per_step_raw": f, "write_kib_per_step": w,
-       "hbm_bytes_per_step_corrected": f * 2048 + w * 1024, "hbm_bytes_per_launch_avg": (f * 2048 + w * 1024) / 62,
+       "frames_per_step": batch, "conv_launches_per_step": n_conv, "fetch_kib_per_step_raw": f, "write_kib_per_step": w,
+       "hbm_bytes_per_step_corrected": f * 2048 + w * 1024, "hbm_bytes_per_launch_avg": (f * 2048 + w * 1024) / n_conv,
        "algorithmic_input_bytes_per_step": alg_in, "algorithmic_output_bytes_per_step": alg_out}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r01_conv_traffic.json"), "w"), indent=1)
+try:
+    pat = f"{tag}_mfma/*/*counter_collection.csv"
+    busy = conv_sum(pat, "SQ_VALU_MFMA_BUSY_CYCLES"); sq = conv_sum(pat, "SQ_BUSY_CYCLES"); gui = conv_sum(pat, "GRBM_GUI_ACTIVE")
+    out["mfma_counters_per_step"] = {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_BUSY_CYCLES": sq, "GRBM_GUI_ACTIVE": gui,
+                                     "note": "sums over the conv dispatches of one step; GRBM_GUI_ACTIVE is the sum over the 8 XCDs"}
+except (IndexError, FileNotFoundError):
+    pass
+name = "r01_conv_traffic.json" if tag == "r01_v3" else f"{tag}_conv_traffic.json"
+json.dump(out, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
 print(json.dumps(out, indent=1))
