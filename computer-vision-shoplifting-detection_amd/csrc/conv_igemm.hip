@@ -625,7 +625,9 @@ std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, i
             const int cover = CT * WC, nblk = (n_ctiles + cover - 1) / cover;
             if (cover >= 2 * n_ctiles && cover > CT) continue;          // more than half of the cout tiles would be padding
             const double waste_c = (double)nblk * cover / n_ctiles;
-            for (int ck = 64; ck >= 16; ck >>= 1) {
+            // staged channels per chunk, in 4-byte units; the fp16 kernels (2 channels per unit) also get 128: their K loop
+            // is so short that the two barriers + pipeline refill per chunk show, above all in the 1x1 layers
+            for (int ck = half ? 128 : 64; ck >= 16; ck >>= 1) {
                 if (ck > cin16 && ck != 16) continue;
                 Plan best{}; best.cost = 1e30;
                 for (int TW = 1; TW <= P && TW <= W; ++TW) {
@@ -715,6 +717,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
                        : (p.version == 3 ? pick_stream(p.CT, p.buf_floats) : pick_kernel(c.k, c.stride, p.CT, p.WP, p.version));
     if (!fn) return "conv: no kernel instance";
     a.zeros = c.zeros; a.lds_buf_floats = p.buf_floats;
+    if (half && p.version == 1) { static const int ex = env_int("MI355_F16_EXP", 0); a.lds_buf_floats = ex; }
     a.TW = p.TW; a.TH = p.TH;
     a.tiles_x = (a.Wout + p.TW - 1) / p.TW; a.tiles_y = (a.Hout + p.TH - 1) / p.TH;
     a.TWin = (p.TW - 1) * c.stride + c.k;
@@ -723,7 +726,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     a.inv_TW = 1.0f / (float)p.TW; a.inv_TWin = 1.0f / (float)a.TWin;
     // plans count staged channels in 4-byte units; the fp16 kernels stage twice as many channels in the same bytes
     a.ck = half ? 2 * p.ck : p.ck; a.ldp = half ? a.ck + 8 : a.ck + 4;
-    a.ck4_shift = (p.ck == 64 ? 4 : p.ck == 32 ? 3 : 2);
+    a.ck4_shift = (p.ck == 128 ? 5 : p.ck == 64 ? 4 : p.ck == 32 ? 3 : 2);
     const int WC = 4 / p.WP;
     out->fn = (const void*)fn;
     a.n_tiles_total = (int)((long)B * a.tiles_x * a.tiles_y);

@@ -21,6 +21,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+// SiLU for the fp16-storage path: x * rcp(1 + 2^(-x log2 e)) on the hardware transcendental units (v_exp_f32 / v_rcp_f32,
+// ~1e-7 relative error, far below the fp16 rounding that follows).  The fp32 path keeps det_silu (libm-free, IEEE
+// division, ~35 VALU instructions) because it has to match the C oracle bit for bit; here that epilogue would cost
+// two thirds of the K loop's MFMA time.
+__device__ __forceinline__ float fast_silu(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896341f);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
 // first cout of the 4 consecutive couts lane group g holds for cout tile `ctile` (see conv_f16_pairs)
 __device__ __forceinline__ int tile_cout0(int ctile, int g, bool pairs) {
     return pairs ? ((ctile >> 1) * 32 + 8 * g + 4 * (ctile & 1)) : (ctile * 16 + 4 * g);
@@ -37,7 +46,7 @@ __device__ __forceinline__ void store_tiles_f16(const ConvKArgs& a, f32x4 (&acc)
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
             f32x4 v = acc[ct][pt] + bias4[ct];
-            if (a.act) { v[0] = det_silu(v[0]); v[1] = det_silu(v[1]); v[2] = det_silu(v[2]); v[3] = det_silu(v[3]); }
+            if (a.act) { v[0] = fast_silu(v[0]); v[1] = fast_silu(v[1]); v[2] = fast_silu(v[2]); v[3] = fast_silu(v[3]); }
             acc[ct][pt] = v;
         }
     if (!a.out_f32 && pairs && (CT % 2 == 0)) {
@@ -140,10 +149,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(ConvKArgs a) {
     const int ck8m = (a.ck >> 3) - 1;
     const int total_v = a.npix_in << a.ck4_shift;          // 16-byte slots of one staged chunk
 
+    const int exp_flags = a.lds_buf_floats;      // diagnostics only (MI355_F16_EXP): 1 skip staging, 2 weights not re-fetched, 4 no stores
     for (int c0 = 0; c0 < a.Cin; c0 += a.ck) {
         if (c0) __syncthreads();
         // stage the halo tile, channels [c0, c0+ck): 8 loads per thread in flight, zero page outside the image / beyond Cin
-        for (int base = 0; base < total_v; base += 8 * 256) {
+        for (int base = 0; base < ((exp_flags & 1) ? 0 : total_v); base += 8 * 256) {
             f16x8 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -169,35 +179,26 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(ConvKArgs a) {
         const int rem = a.Cin - c0;
         const int nkk = ((rem < a.ck ? rem : a.ck) + 31) >> 5;
         const int cib0 = c0 >> 5;
-        // (k-block, tap) flattened into one loop of pipeline steps; weight fragments (L2) prefetched WD steps ahead, pixel
-        // fragments (LDS) one step ahead; both cursors clamp at the last step so every load is unconditional
-        constexpr int WD = (CT <= 2) ? 4 : 3;
-        const int n_it = nkk * TAPS;
+        // K loop.  One f16 MFMA retires a 1-KiB fragment pair in 16 cycles, so a pipeline step (CT*PT MFMAs) is 8x shorter
+        // than in the fp32 kernel and the per-step bookkeeping decides the rate: the taps are unrolled at compile time
+        // (their LDS / weight offsets are loop-invariant scalars), the only running scalars are the current and the next
+        // k-block base, and nothing in the loop branches.  Fragments travel through rings of R = 3 register sets:
+        // weights (L2) are fetched two steps ahead, pixels (LDS) one step ahead; loads past the last k-block of the
+        // chunk re-read the last one (unconditional loads keep the s_waitcnt counters counted).
+        constexpr int R = 3;
         const int wstep = a.cib * 512;
-        int w_it = 0, w_kw = 0, w_kh = 0, w_kk = 0, w_off = cib0 * 512;
-        int x_it = 0, x_kw = 0, x_kh = 0, x_kk = 0, x_off = 0;
-        f16x8 wf[WD][CT], xf[2][PT];
-        auto load_w = [&](f16x8* w) {
+        const int klast = nkk - 1;
+        f16x8 wf[R][CT], xf[R][PT];
+        auto opaque = [](int v) { asm volatile("" : "+s"(v)); return v; };     // keeps a scalar sum out of LICM's hands
+        auto load_w = [&](f16x8* w, int off) {
+            if (exp_flags & 8) return;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f16x8*)(wbase[ct] + w_off);
-            if (w_it + 1 < n_it) {
-                ++w_it; ++w_kw; w_off += wstep;
-                if (w_kw == KS) {
-                    w_kw = 0; ++w_kh;
-                    if (w_kh == KS) { w_kh = 0; ++w_kk; w_off = (cib0 + w_kk) * 512; }
-                }
-            }
+            for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f16x8*)(wbase[ct] + off);
         };
-        auto load_x = [&](f16x8* x) {
+        auto load_x = [&](f16x8* x, int off) {
+            if (exp_flags & 16) return;
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) x[pt] = *(const f16x8*)__builtin_assume_aligned(lds_h + xoff[pt] + x_off, 16);
-            if (x_it + 1 < n_it) {
-                ++x_it; ++x_kw; x_off += a.ldp;
-                if (x_kw == KS) {
-                    x_kw = 0; ++x_kh; x_off += (a.TWin - KS) * a.ldp;
-                    if (x_kh == KS) { x_kh = 0; ++x_kk; x_off = x_kk * 32; }
-                }
-            }
+            for (int pt = 0; pt < PT; ++pt) x[pt] = *(const f16x8*)__builtin_assume_aligned(lds_h + xoff[pt] + off, 16);
         };
         auto mma = [&](const f16x8* w, const f16x8* x) {
 #pragma unroll
@@ -206,20 +207,53 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(ConvKArgs a) {
                 for (int pt = 0; pt < PT; ++pt)
                     acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ct], x[pt], acc[ct][pt], 0, 0, 0);
         };
+        if constexpr (TAPS > 1) {
+            static_assert(TAPS % R == 0, "ring slots must line up across k-blocks");
+            int xt[TAPS], wt[TAPS];
 #pragma unroll
-        for (int j = 0; j < WD - 1; ++j) load_w(wf[j]);
-        load_x(xf[0]);
-        constexpr int UN = 2 * WD;                          // unroll: a common multiple of the two ring depths
-        for (int it = 0; it < n_it; it += UN) {
+            for (int t = 0; t < TAPS; ++t) { xt[t] = ((t / KS) * a.TWin + (t % KS)) * a.ldp; wt[t] = t * wstep; }
+            const bool frozen = (exp_flags & 2) != 0;
+            // prologue: steps 0 and 1 of k-block 0
+            load_w(wf[0], cib0 * 512 + wt[0]);
+            load_w(wf[1], cib0 * 512 + wt[1]);
+            load_x(xf[0], xt[0]);
+            for (int kb = 0; kb < nkk; ++kb) {
+                const int kn = kb < klast ? kb + 1 : klast;
+                const int wk = opaque((cib0 + (frozen ? 0 : kb)) * 512), wkn = opaque((cib0 + (frozen ? 0 : kn)) * 512);
+                const int xk = opaque(kb * 32), xkn = opaque(kn * 32);
 #pragma unroll
-            for (int j = 0; j < UN; ++j) {
-                load_w(wf[(j + WD - 1) % WD]);
-                load_x(xf[(j + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (it + j < n_it) mma(wf[j % WD], xf[j & 1]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int t = 0; t < TAPS; ++t) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int tw = (t + 2) % TAPS, tx = (t + 1) % TAPS;
+                    load_w(wf[(t + 2) % R], opaque(((t + 2) >= TAPS ? wkn : wk) + wt[tw]));
+                    load_x(xf[(t + 1) % R], opaque(((t + 1) >= TAPS ? xkn : xk) + xt[tx]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(wf[t % R], xf[t % R]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            // pointwise: a step is a k-block; R k-blocks per trip so that the ring slots are compile-time
+            auto koff = [&](int kb) { return kb < klast ? kb : klast; };
+            load_w(wf[0], (cib0 + koff(0)) * 512);
+            load_w(wf[1], (cib0 + koff(1)) * 512);
+            load_x(xf[0], 0);
+            for (int kb0 = 0; kb0 < nkk; kb0 += R) {
+#pragma unroll
+                for (int t = 0; t < R; ++t) {
+                    const int kw = koff(kb0 + t + 2), kx = koff(kb0 + t + 1);
+                    load_w(wf[(t + 2) % R], opaque((cib0 + ((exp_flags & 2) ? 0 : kw)) * 512));
+                    load_x(xf[(t + 1) % R], opaque(kx * 32));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kb0 + t < nkk) mma(wf[t % R], xf[t % R]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
+    }
+    if (exp_flags & 4) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) ok[pt] = ok[pt] && acc[0][pt][0] == 12345.678f;
     }
     store_tiles_f16<PT, CT>(a, acc, bias4, lane, ct0, po, ok);
 }

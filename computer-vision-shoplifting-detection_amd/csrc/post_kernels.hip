@@ -337,8 +337,59 @@ __device__ void bitonic_sort(unsigned long long* v, int n2, int tid, int nthread
 }
 
 constexpr int NMS_LDS_KEYS = 4096;
+constexpr int NMS_SORT_THREADS = 1024;
 
-__global__ __launch_bounds__(256) void nms_sort_kernel(NmsArgs a, int* cand_counts) {
+// compare-exchange steps j = j_hi, j_hi/2, .. 1 of merge stage k on the LDS-resident chunk [base, base + NMS_LDS_KEYS) of a
+// longer sequence (directions follow the GLOBAL index)
+__device__ void bitonic_steps_lds(unsigned long long* sk, int base, int k, int j_hi, int tid) {
+    for (int j = j_hi; j > 0; j >>= 1) {
+        for (int l = tid; l < NMS_LDS_KEYS; l += NMS_SORT_THREADS) {
+            const int lxj = l ^ j;
+            if (lxj > l) {
+                const unsigned long long a = sk[l], b = sk[lxj];
+                const bool up = ((base + l) & k) == 0;
+                if ((a > b) == up) { sk[l] = b; sk[lxj] = a; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// More candidates than fit in LDS (conf ~0.001 validation-style calls, or 1280x1280 inputs): the classic hybrid -- every
+// compare-exchange at distance < NMS_LDS_KEYS runs on LDS-resident chunks, only the few long-distance steps of the last
+// merge stages touch global memory (3 global round trips for 8192 keys instead of 91).
+__device__ void bitonic_sort_hybrid(unsigned long long* keys, unsigned long long* sk, int n2, int tid) {
+    constexpr int C = NMS_LDS_KEYS;
+    for (int base = 0; base < n2; base += C) {                       // stages k = 2 .. C: chunk-local
+        for (int l = tid; l < C; l += NMS_SORT_THREADS) sk[l] = keys[base + l];
+        __syncthreads();
+        for (int k = 2; k <= C; k <<= 1) bitonic_steps_lds(sk, base, k, k >> 1, tid);
+        for (int l = tid; l < C; l += NMS_SORT_THREADS) keys[base + l] = sk[l];
+        __syncthreads();
+    }
+    for (int k = 2 * C; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j >= C; j >>= 1) {                      // partners live in different chunks
+            for (int i = tid; i < n2; i += NMS_SORT_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+        for (int base = 0; base < n2; base += C) {
+            for (int l = tid; l < C; l += NMS_SORT_THREADS) sk[l] = keys[base + l];
+            __syncthreads();
+            bitonic_steps_lds(sk, base, k, C >> 1, tid);
+            for (int l = tid; l < C; l += NMS_SORT_THREADS) keys[base + l] = sk[l];
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(NMS_SORT_THREADS) void nms_sort_kernel(NmsArgs a, int* cand_counts) {
     __shared__ unsigned long long skeys[NMS_LDS_KEYS];
     __shared__ int scount;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -346,7 +397,7 @@ __global__ __launch_bounds__(256) void nms_sort_kernel(NmsArgs a, int* cand_coun
     if (tid == 0) scount = 0;
     __syncthreads();
     const float2* best = a.best + (size_t)b * a.A;
-    for (int an = tid; an < a.A; an += 256) {
+    for (int an = tid; an < a.A; an += NMS_SORT_THREADS) {
         const float2 bc = best[an];
         bool ok = bc.x > a.conf;
         if (ok && a.class_mask) { const int c = (int)bc.y; ok = (a.class_mask[c >> 5] >> (c & 31)) & 1u; }
@@ -359,16 +410,16 @@ __global__ __launch_bounds__(256) void nms_sort_kernel(NmsArgs a, int* cand_coun
     const int n = scount;
     int n2 = 1;
     while (n2 < n) n2 <<= 1;
-    for (int i = n + tid; i < n2; i += 256) keys[i] = ~0ull;
+    for (int i = n + tid; i < n2; i += NMS_SORT_THREADS) keys[i] = ~0ull;
     __syncthreads();
     if (n2 > 1) {
         if (n2 <= NMS_LDS_KEYS) {
-            for (int i = tid; i < n2; i += 256) skeys[i] = keys[i];
+            for (int i = tid; i < n2; i += NMS_SORT_THREADS) skeys[i] = keys[i];
             __syncthreads();
-            bitonic_sort(skeys, n2, tid, 256);
-            for (int i = tid; i < n; i += 256) keys[i] = skeys[i];
+            bitonic_sort(skeys, n2, tid, NMS_SORT_THREADS);
+            for (int i = tid; i < n; i += NMS_SORT_THREADS) keys[i] = skeys[i];
         } else {
-            bitonic_sort(keys, n2, tid, 256);
+            bitonic_sort_hybrid(keys, skeys, n2, tid);
         }
     }
     if (tid == 0) cand_counts[b] = n < a.max_nms ? n : a.max_nms;     // "if n > max_nms: keep the top max_nms by conf"
@@ -470,7 +521,7 @@ const char* launch_nms(const NmsArgs& a, hipStream_t st) {
     if (a.max_det < 1 || a.max_det > NMS_MAX_DET) return "nms: max_det must be in [1, 1024]";
     // cand_counts lives in the tail of out_counts' allocation: out_counts[B .. 2B)
     int* cand_counts = a.out_counts + a.B;
-    hipLaunchKernelGGL(nms_sort_kernel, dim3(a.B), dim3(256), 0, st, a, cand_counts);
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(a.B), dim3(NMS_SORT_THREADS), 0, st, a, cand_counts);
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(a.B), dim3(64), 0, st, a, cand_counts);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);

@@ -87,3 +87,30 @@ def test_scale_back_and_xywhn():
     assert k.tolist() == [[[200.0, 200.0, 0.8999999761581421]]]
     xywhn = O.boxes_xywhn(torch.tensor([[200.0, 200.0, 600.0, 400.0]]), (720, 1280))
     np.testing.assert_allclose(xywhn.numpy(), [[400 / 1280, 300 / 720, 400 / 1280, 200 / 720]], rtol=1e-7)
+
+
+def test_half_storage_mode_of_the_oracle(v8n):
+    """oracle half=True (the engine's half contract): weights of every conv but the stem and every stored activation are
+    fp16 values; the head logits stay fp32; results stay close to fp32; fp32 mode is untouched by the option."""
+    import torch
+    from oracle import yolo_oracle as O
+    from tools import synth
+    sd = v8n[1]
+    frames = synth.synthetic_frames(1, 96, 96, seed=2)
+    x = O.preprocess(list(frames), 96)
+    o32, o16 = O.OracleModel("yolov8n", sd), O.OracleModel("yolov8n", sd, half=True)
+    w16, _ = o16._fused_conv("model.2.cv1")
+    assert torch.equal(w16, w16.half().float())                       # fp16-representable weights
+    w_stem16, _ = o16._fused_conv("model.0")
+    w_stem32, _ = o32._fused_conv("model.0")
+    assert torch.equal(w_stem16, w_stem32)                            # the u8 stem keeps fp32 weights
+    feats = o16.forward(x, return_features=True)
+    for f in feats:
+        assert torch.equal(f, f.half().float())                       # stored activations are fp16 values
+    a, b = o32.forward(x), o16.forward(x)
+    assert a.shape == b.shape and not torch.equal(a, b)
+    assert (a[:, :4] - b[:, :4]).abs().median() < 0.1                 # fp16 rounding noise only (px)
+    assert (a[:, 4:] - b[:, 4:]).abs().max() < 0.05
+    # the residual add is rounded once, after the add (Bottleneck with shortcut)
+    y = o16.Bottleneck(o16._store(torch.randn(1, 16, 8, 8)), "model.2.m.0", True)
+    assert torch.equal(y, y.half().float())

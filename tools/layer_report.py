@@ -14,7 +14,7 @@ chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 size = int(sys.argv[4]) if len(sys.argv) > 4 else 640
 es = float(sys.argv[5]) if len(sys.argv) > 5 else 4.0      # activation element size: 4 = fp32, 2 = the half=True engine
 prog = build_program(*parse_model_name(model))
-rows = [r for r in csv.DictReader(open(path)) if "mi355::" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(path)) if "mi355" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 seq = []
 for op in prog.ops:
