@@ -524,6 +524,149 @@ __global__ __launch_bounds__(256) void conv1x1_stream_f32(ConvKArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- v4 (1x1 only)
+// Pointwise convs have a short K loop per staged chunk (Cin/16 steps), so in v1 the block spends as long waiting for its
+// activation loads as it spends on MFMAs.  v4 is a PERSISTENT, software-pipelined form of v1 for k = 1: the unit of work
+// is one (pixel tile, channel chunk) item; while the MFMAs of item i run from LDS, the global loads of item i+1 are
+// already in flight into registers, and the stores of the previous tile drain behind them.  vmcnt retires in order, so
+// the order of issue is what makes this work: the chunk's weight fragments (all of them: a 1x1 chunk has at most 4 k-blocks)
+// are requested BEFORE the prefetch, hence waiting for them never waits for the prefetch.
+// Same canonical accumulation order as v1 (16-channel block outer, step s, k-group g): same bits.
+template <int PT, int CT, int WP, bool SINGLE, int NKK>   // SINGLE: Cin fits one chunk -> every item ends a tile; NKK: k-blocks per chunk
+__global__ __launch_bounds__(256) void conv1x1_pipe_f32(ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int WC = 4 / WP, NV = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave % WP, wc = wave / WP, g = lane >> 4;
+    const int ct0 = (blockIdx.y * WC + wc) * CT;
+    const int P = a.TW, total = a.Wout;
+    const int sh = a.ck4_shift, ck4m = (a.ck >> 2) - 1, tile_v = P << sh;
+    const int nst = SINGLE ? 1 : (a.Cin + a.ck - 1) / a.ck;
+    const int n_tiles = a.n_tiles_total;
+    const int my_tiles = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int n_items = my_tiles * nst;
+    if (n_items == 0) return;
+
+    auto prefetch = [&](int item, f32x4 (&v)[NV]) {      // item >= n_items: every lane reads the zero page (loads stay unconditional)
+        const bool live = item < n_items;
+        const int ti = SINGLE ? item : item / nst;
+        const int p0 = ((int)blockIdx.x + ti * (int)gridDim.x) * P;
+        const int c0 = SINGLE ? 0 : (item - ti * nst) * a.ck;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int idx = u * 256 + tid;
+            const int pix = idx >> sh, q = idx & ck4m;
+            const int p = p0 + pix, c = c0 + 4 * q;
+            const bool inb = live && idx < tile_v && p < total && c < a.cin4;
+            const float* src = inb ? a.src + (size_t)p * a.src_cs + c : a.zeros;
+            v[u] = *(const f32x4*)src;
+        }
+    };
+    auto commit = [&](const f32x4 (&v)[NV]) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int idx = u * 256 + tid;
+            if (idx < tile_v) *(f32x4*)(lds + (idx >> sh) * a.ldp + 4 * (idx & ck4m)) = v[u];
+        }
+    };
+    int xoff[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) xoff[pt] = ((wp * PT + pt) * 16 + (lane & 15)) * a.ldp + 4 * g;
+    const float* wbase[CT];
+    f32x4 bias4[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        wbase[ct] = a.wpk + (size_t)ctile * a.cib * 256 + lane * 4;
+        bias4[ct] = *(const f32x4*)(a.bias + ctile * 16 + g * 4);
+    }
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 pv[NV];
+    prefetch(0, pv);
+    commit(pv);
+    __syncthreads();
+    f32x4 w[NKK][CT];
+    auto load_w = [&](int item) {
+        const int st = SINGLE ? 0 : item % nst;
+        const int cib0 = (st * a.ck) >> 4;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int kb = cib0 + kk < a.cib ? cib0 + kk : a.cib - 1;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) w[kk][ct] = *(const f32x4*)(wbase[ct] + kb * 256);
+        }
+    };
+    load_w(0);
+    prefetch(1, pv);
+    for (int item = 0; item < n_items; ++item) {
+        const int st = SINGLE ? 0 : item % nst;
+        const int c0 = st * a.ck;
+        const int rem = a.Cin - c0;
+        const int nkk = ((rem < a.ck ? rem : a.ck) + 15) >> 4;
+        // ---- K loop of this item: pixel fragments one k-block ahead (two register sets), weights already in registers
+        f32x4 xf[2][PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) xf[0][pt] = *(const f32x4*)__builtin_assume_aligned(lds + xoff[pt], 16);
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int kn = (kk + 1 < nkk ? kk + 1 : nkk - 1) * 16;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) xf[(kk + 1) & 1][pt] = *(const f32x4*)__builtin_assume_aligned(lds + xoff[pt] + kn, 16);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk < nkk) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt)
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kk][ct][s], xf[kk & 1][pt][s], acc[ct][pt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                   // every wave is done reading this item's LDS image
+        commit(pv);                                        // item + 1 (zeros after the last one)
+        load_w(item + 1 < n_items ? item + 1 : item);      // requested before the stores and the next prefetch
+        if (SINGLE || st == nst - 1) {
+            // ---- epilogue of the tile that just finished (same math as conv_epilogue, flattened pixel index)
+            const int ti = SINGLE ? item : item / nst;
+            const int p0 = ((int)blockIdx.x + ti * (int)gridDim.x) * P;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int lp = (wp * PT + pt) * 16 + (lane & 15);
+                const int p = p0 + lp;
+                const bool ok = lp < P && p < total;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int c = (ct0 + ct) * 16 + g * 4;
+                    f32x4 v = acc[ct][pt] + bias4[ct];
+                    acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (!ok || c >= a.Cout) continue;
+                    if (a.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                    float* d = a.dst + (size_t)p * a.dst_cs + c;
+                    if (c + 3 < a.Cout) {
+                        if (a.res) v += *(const f32x4*)(a.res + (size_t)p * a.res_cs + c);
+                        *(f32x4*)d = v;
+                    } else {
+                        for (int i = 0; i < 4 && c + i < a.Cout; ++i) {
+                            float r = v[i];
+                            if (a.res) r += a.res[(size_t)p * a.res_cs + c + i];
+                            d[i] = r;
+                        }
+                    }
+                }
+            }
+        }
+        prefetch(item + 2, pv);
+        __syncthreads();                                   // item + 1's LDS image is complete
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 size_t packed_weight_floats(int cout, int cin, int k) {
     return (size_t)((cout + 15) / 16) * k * k * ((cin + 15) / 16) * 256;
@@ -584,6 +727,24 @@ KernelFn pick_stream(int CT, int PT) {
     if (CT == 4 && PT == 2) return &conv1x1_stream_f32<2, 4>;
     if (CT == 4 && PT == 4) return &conv1x1_stream_f32<4, 4>;
     return nullptr;
+}
+
+template <bool SINGLE, int NKK>
+KernelFn pick_pipe_s(int CT, int WP) {
+#define MI355_CASE4(ct, wp) if (CT == ct && WP == wp) return &conv1x1_pipe_f32<4, ct, wp, SINGLE, NKK>;
+    MI355_CASE4(1, 1) MI355_CASE4(2, 1) MI355_CASE4(4, 1)
+    MI355_CASE4(1, 2) MI355_CASE4(2, 2) MI355_CASE4(4, 2)
+    MI355_CASE4(1, 4) MI355_CASE4(2, 4) MI355_CASE4(4, 4)
+#undef MI355_CASE4
+    return nullptr;
+}
+
+KernelFn pick_pipe(int CT, int WP, bool single, int ck) {
+    if (ck > 64) {                       // 8 k-blocks per chunk: weights of a chunk = 8*CT fragments in registers
+        if (CT > 2) return nullptr;
+        return single ? pick_pipe_s<true, 8>(CT, WP) : pick_pipe_s<false, 8>(CT, WP);
+    }
+    return single ? pick_pipe_s<true, 4>(CT, WP) : pick_pipe_s<false, 4>(CT, WP);
 }
 
 KernelFn pick_kernel(int ks, int stride, int CT, int WP, int version) {
@@ -673,6 +834,25 @@ std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, i
                 out.push_back(p3);
             }
     }
+    if (ks == 1 && allow_v2 && !half) {   // persistent software-pipelined pointwise kernel (v4)
+        static const int use_v4 = env_int("MI355_CONV_V4", 1);
+        const int wps[3] = {1, 2, 4}, cts[3] = {1, 2, 4}, cks[4] = {128, 64, 32, 16};
+        for (int wi = 0; wi < 3 && use_v4; ++wi)
+            for (int ci = 0; ci < 3; ++ci)
+                for (int ki = 0; ki < 4; ++ki) {
+                    const int WP = wps[wi], WC = 4 / WP, CT = cts[ci], ck = cks[ki], P = WP * 64;
+                    const int cover = CT * WC, nblk = (n_ctiles + cover - 1) / cover;
+                    if (cover >= 2 * n_ctiles && cover > CT) continue;
+                    if (ck > cin16 && ck != 16) continue;
+                    if (P * ck / 4 > 2048) continue;                       // 8 prefetch registers (float4) per thread
+                    if (ck > 64 && CT > 2) continue;                       // a chunk's weights live in registers: 8 k-blocks x CT fragments
+                    const size_t lds = (size_t)P * (ck + 4) * 4;
+                    const int stages = (cin16 + ck - 1) / ck;
+                    Plan p4{CT, WP, P, 1, ck, lds, 0.0, 4, 0, 0};
+                    p4.cost = (double)nblk * cover / n_ctiles * (1.0 + 0.03 * (stages - 1)) * (1.0 + 0.02 * nblk) * 0.8;
+                    out.push_back(p4);
+                }
+    }
     std::sort(out.begin(), out.end(), [](const Plan& a, const Plan& b) { return a.cost < b.cost; });
     return out;
 }
@@ -714,7 +894,8 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
         a.Hin = c.Hin; a.Win = c.Win; a.Hout = c.Hout; a.Wout = c.Wout;
     }
     KernelFn fn = half ? (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.version == 3 ? p.buf_floats : p.PT)
-                       : (p.version == 3 ? pick_stream(p.CT, p.buf_floats) : pick_kernel(c.k, c.stride, p.CT, p.WP, p.version));
+                       : (p.version == 3 ? pick_stream(p.CT, p.buf_floats)
+                          : p.version == 4 ? pick_pipe(p.CT, p.WP, c.Cin <= p.ck, p.ck) : pick_kernel(c.k, c.stride, p.CT, p.WP, p.version));
     if (!fn) return "conv: no kernel instance";
     a.zeros = c.zeros; a.lds_buf_floats = p.buf_floats;
     if (half && p.version == 1) { static const int ex = env_int("MI355_F16_EXP", 0); a.lds_buf_floats = ex; }
@@ -731,6 +912,11 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     out->fn = (const void*)fn;
     a.n_tiles_total = (int)((long)B * a.tiles_x * a.tiles_y);
     out->grid_x = (unsigned)a.n_tiles_total;
+    if (p.version == 4) {      // persistent: a few resident blocks per CU, each walks tiles blockIdx.x, + gridDim.x, ...
+        const int gy = std::max(1, (a.n_ctiles + p.CT * (4 / p.WP) - 1) / (p.CT * (4 / p.WP)));
+        const int per_cu = std::max(1, std::min(4, (int)((size_t)(160 * 1024) / std::max<size_t>(p.lds, 1))));
+        out->grid_x = std::min(out->grid_x, (unsigned)std::max(1, 256 * per_cu / gy));
+    }
     if (p.version == 2) {      // persistent: as many blocks as stay resident (LDS-limited), each loops over tiles
         const int per_cu = std::max(1, std::min(6, (int)((size_t)(160 * 1024) / std::max<size_t>(p.lds, 1))));
         const unsigned cap = (unsigned)std::max(1, 256 * per_cu / (int)std::max(1, (a.n_ctiles + p.CT * (4 / p.WP) - 1) / (p.CT * (4 / p.WP))));
