@@ -38,6 +38,7 @@ __host__ __device__ inline bool conv_f16_pairs(int cout) { return (cout % 32) ==
 void floats_to_halfs(const float* in, uint16_t* out_bits, size_t n);     // round-to-nearest-even
 void halfs_to_floats(const uint16_t* in_bits, float* out, size_t n);
 const void* pick_conv_kernel_f16(int ks, int stride, int CT, int WP, int version, int stream_pt);
+const void* pick_conv_pipe_f16(int CT, int WP, bool single, bool nkk8);
 struct ConvKArgs {
     const float* src; float* dst; const float* res; const float* wpk; const float* bias;
     int src_cs, dst_cs, res_cs;

@@ -834,18 +834,18 @@ std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, i
                 out.push_back(p3);
             }
     }
-    if (ks == 1 && allow_v2 && !half) {   // persistent software-pipelined pointwise kernel (v4)
+    if (ks == 1 && allow_v2) {   // persistent software-pipelined pointwise kernel (v4); ck in 4-byte units (fp16: 2 channels each)
         static const int use_v4 = env_int("MI355_CONV_V4", 1);
-        const int wps[3] = {1, 2, 4}, cts[3] = {1, 2, 4}, cks[4] = {128, 64, 32, 16};
+        const int wps[3] = {1, 2, 4}, cts[4] = {1, 2, 4, 3}, cks[4] = {128, 64, 32, 16};
         for (int wi = 0; wi < 3 && use_v4; ++wi)
-            for (int ci = 0; ci < 3; ++ci)
+            for (int ci = 0; ci < (half ? 4 : 3); ++ci)
                 for (int ki = 0; ki < 4; ++ki) {
                     const int WP = wps[wi], WC = 4 / WP, CT = cts[ci], ck = cks[ki], P = WP * 64;
                     const int cover = CT * WC, nblk = (n_ctiles + cover - 1) / cover;
                     if (cover >= 2 * n_ctiles && cover > CT) continue;
                     if (ck > cin16 && ck != 16) continue;
                     if (P * ck / 4 > 2048) continue;                       // 8 prefetch registers (float4) per thread
-                    if (ck > 64 && CT > 2) continue;                       // a chunk's weights live in registers: 8 k-blocks x CT fragments
+                    if (ck > 64 && CT > (half ? 3 : 2)) continue;          // a chunk's weights live in registers: 8 k-blocks x CT fragments
                     const size_t lds = (size_t)P * (ck + 4) * 4;
                     const int stages = (cin16 + ck - 1) / ck;
                     Plan p4{CT, WP, P, 1, ck, lds, 0.0, 4, 0, 0};
@@ -893,11 +893,13 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     } else {
         a.Hin = c.Hin; a.Win = c.Win; a.Hout = c.Hout; a.Wout = c.Wout;
     }
-    KernelFn fn = half ? (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.version == 3 ? p.buf_floats : p.PT)
+    KernelFn fn = half ? (p.version == 4 ? (KernelFn)pick_conv_pipe_f16(p.CT, p.WP, (c.Cin + 1) / 2 <= p.ck, p.ck > 64)
+                                         : (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.version == 3 ? p.buf_floats : p.PT))
                        : (p.version == 3 ? pick_stream(p.CT, p.buf_floats)
                           : p.version == 4 ? pick_pipe(p.CT, p.WP, c.Cin <= p.ck, p.ck) : pick_kernel(c.k, c.stride, p.CT, p.WP, p.version));
     if (!fn) return "conv: no kernel instance";
     a.zeros = c.zeros; a.lds_buf_floats = p.buf_floats;
+    if (half && p.version == 4) a.lds_buf_floats = 0;
     if (half && p.version == 1) { static const int ex = env_int("MI355_F16_EXP", 0); a.lds_buf_floats = ex; }
     a.TW = p.TW; a.TH = p.TH;
     a.tiles_x = (a.Wout + p.TW - 1) / p.TW; a.tiles_y = (a.Hout + p.TH - 1) / p.TH;

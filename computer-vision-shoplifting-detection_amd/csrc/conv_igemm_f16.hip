@@ -329,6 +329,130 @@ __global__ __launch_bounds__(256) void conv1x1_stream_f16(ConvKArgs a) {
     store_tiles_f16<PT, CT>(a, acc, bias4, lane, ct0, po, ok);
 }
 
+// Persistent, software-pipelined pointwise kernel: the fp16 form of conv1x1_pipe_f32 (conv_igemm.hip, "v4").  Unit of work =
+// one (pixel tile, channel chunk) item; the loads of item i+1 are in flight into registers while the MFMAs of item i run
+// from LDS.  All weight fragments of a chunk (NKK k-blocks x CT) are requested before the prefetch, so the in-order
+// vmcnt never makes the K loop wait for the prefetch.
+template <int PT, int CT, int WP, bool SINGLE, int NKK>
+__global__ __launch_bounds__(256) void conv1x1_pipe_f16(ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds_h[];
+    constexpr int WC = 4 / WP, NV = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave % WP, wc = wave / WP, g = lane >> 4;
+    const int ct0 = (blockIdx.y * WC + wc) * CT;
+    const int P = a.TW, total = a.Wout;
+    const int sh = a.ck4_shift, ck8m = (a.ck >> 3) - 1, tile_v = P << sh;
+    const int nst = SINGLE ? 1 : (a.Cin + a.ck - 1) / a.ck;
+    const int n_tiles = a.n_tiles_total;
+    const int my_tiles = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int n_items = my_tiles * nst;
+    if (n_items == 0) return;
+    const _Float16* srcp = (const _Float16*)a.src;
+    const _Float16* zeros = (const _Float16*)a.zeros;
+
+    auto prefetch = [&](int item, f16x8 (&v)[NV]) {      // item >= n_items: every lane reads the zero page
+        const bool live = item < n_items;
+        const int ti = SINGLE ? item : item / nst;
+        const int p0 = ((int)blockIdx.x + ti * (int)gridDim.x) * P;
+        const int c0 = SINGLE ? 0 : (item - ti * nst) * a.ck;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int idx = u * 256 + tid;
+            const int pix = idx >> sh, q = idx & ck8m;
+            const int p = p0 + pix, c = c0 + 8 * q;
+            const bool inb = live && idx < tile_v && p < total && c < a.cin4;
+            const _Float16* src = inb ? srcp + (size_t)p * a.src_cs + c : zeros;
+            v[u] = *(const f16x8*)src;
+        }
+    };
+    auto commit = [&](const f16x8 (&v)[NV]) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int idx = u * 256 + tid;
+            if (idx < tile_v) *(f16x8*)(lds_h + (idx >> sh) * a.ldp + 8 * (idx & ck8m)) = v[u];
+        }
+    };
+    int xoff[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) xoff[pt] = ((wp * PT + pt) * 16 + (lane & 15)) * a.ldp + 8 * g;
+    const _Float16* wbase[CT];
+    f32x4 bias4[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        wbase[ct] = (const _Float16*)a.wpk + (size_t)ctile * a.cib * 512 + lane * 8;
+        bias4[ct] = *(const f32x4*)(a.bias + tile_cout0(ctile, g, conv_f16_pairs(a.Cout)));
+    }
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f16x8 pv[NV];
+    prefetch(0, pv);
+    commit(pv);
+    __syncthreads();
+    f16x8 w[NKK][CT];
+    auto load_w = [&](int item) {
+        const int st = SINGLE ? 0 : item % nst;
+        const int cib0 = (st * a.ck) >> 5;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int kb = cib0 + kk < a.cib ? cib0 + kk : a.cib - 1;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) w[kk][ct] = *(const f16x8*)(wbase[ct] + kb * 512);
+        }
+    };
+    load_w(0);
+    prefetch(1, pv);
+    for (int item = 0; item < n_items; ++item) {
+        const int st = SINGLE ? 0 : item % nst;
+        const int c0 = st * a.ck;
+        const int rem = a.Cin - c0;
+        const int nkk = ((rem < a.ck ? rem : a.ck) + 31) >> 5;
+        f16x8 xf[2][PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) xf[0][pt] = *(const f16x8*)__builtin_assume_aligned(lds_h + xoff[pt], 16);
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int kn = (kk + 1 < nkk ? kk + 1 : nkk - 1) * 32;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) xf[(kk + 1) & 1][pt] = *(const f16x8*)__builtin_assume_aligned(lds_h + xoff[pt] + kn, 16);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk < nkk) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt)
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[kk][ct], xf[kk & 1][pt], acc[ct][pt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                   // every wave is done reading this item's LDS image
+        commit(pv);                                        // item + 1 (zeros after the last one)
+        load_w(item + 1 < n_items ? item + 1 : item);      // requested before the stores and the next prefetch
+        if (SINGLE || st == nst - 1) {
+            const int ti = SINGLE ? item : item / nst;
+            const int p0 = ((int)blockIdx.x + ti * (int)gridDim.x) * P;
+            size_t po[PT]; bool ok[PT];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int p = p0 + (wp * PT + pt) * 16 + (lane & 15);
+                ok[pt] = p < total;
+                po[pt] = (size_t)(ok[pt] ? p : 0);
+            }
+            store_tiles_f16<PT, CT>(a, acc, bias4, lane, ct0, po, ok);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        prefetch(item + 2, pv);
+        __syncthreads();                                   // item + 1's LDS image is complete
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 size_t packed_weight_halfs(int cout, int cin, int k) {
     return (size_t)((cout + 15) / 16) * k * k * ((cin + 31) / 32) * 512;
@@ -386,6 +510,27 @@ KernelFn pick_ct_wp_h(int CT, int WP, int PT) {
 }
 
 }  // namespace
+
+namespace {
+template <bool SINGLE, int NKK>
+KernelFn pick_pipe_h(int CT, int WP) {
+#define MI355_CASEP(ct, wp) if (CT == ct && WP == wp) return &conv1x1_pipe_f16<4, ct, wp, SINGLE, NKK>;
+    MI355_CASEP(1, 1) MI355_CASEP(2, 1) MI355_CASEP(3, 1) MI355_CASEP(4, 1)
+    MI355_CASEP(1, 2) MI355_CASEP(2, 2) MI355_CASEP(3, 2) MI355_CASEP(4, 2)
+    MI355_CASEP(1, 4) MI355_CASEP(2, 4) MI355_CASEP(3, 4) MI355_CASEP(4, 4)
+#undef MI355_CASEP
+    return nullptr;
+}
+}  // namespace
+
+// v4 (pipelined pointwise): single = Cin fits one chunk; nkk8 = 8 k-blocks (256 channels) per chunk instead of <= 4
+const void* pick_conv_pipe_f16(int CT, int WP, bool single, bool nkk8) {
+    if (nkk8) {
+        if (CT > 3) return nullptr;
+        return single ? (const void*)pick_pipe_h<true, 8>(CT, WP) : (const void*)pick_pipe_h<false, 8>(CT, WP);
+    }
+    return single ? (const void*)pick_pipe_h<true, 4>(CT, WP) : (const void*)pick_pipe_h<false, 4>(CT, WP);
+}
 
 const void* pick_conv_kernel_f16(int ks, int stride, int CT, int WP, int version, int stream_pt /* v3: PT; v1: 0 or 8 */) {
     if (version == 3) {
