@@ -249,6 +249,175 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- v5
+// v1 made persistent and software-pipelined (the 3x3 / strided form of what v4 does for pointwise convs): a block walks
+// (output tile, channel chunk) items; before the K loop of item i starts, the halo tile of item i+1 is requested into
+// NV registers per thread, and it is written to LDS after the loop -- the HBM/L2 latency of the staging hides under
+// ~10-70k cycles of MFMAs instead of being exposed at the head of every block.  vmcnt retires in order, so the first
+// WD-1 weight fragments of the next item are requested BEFORE the epilogue stores and the prefetch: waiting for them never
+// waits for either.  An fp32 pipeline step is >= 512 cycles, so the prefetch has landed long before the first weight
+// fragment requested after it is needed.  Accumulation order and epilogue are v1's: same bits.
+template <int KS, int STRIDE, int PT, int CT, int WP, bool SINGLE>
+__global__ __launch_bounds__(256) void conv_igemm_f32_v5(ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int WC = 4 / WP, TAPS = KS * KS, NV = 8;
+    constexpr int WD = (CT <= 2) ? 4 : 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave % WP, wc = wave / WP;
+    const int ct0 = (blockIdx.y * WC + wc) * CT;
+    const int npix = a.TW * a.TH;
+    const int nst = SINGLE ? 1 : (a.Cin + a.ck - 1) / a.ck;
+    const int n_tiles = a.n_tiles_total;
+    const int my_tiles = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int n_items = my_tiles * nst;
+    if (n_items == 0) return;
+    const int ck4m = (a.ck >> 2) - 1;
+    const int total_f4 = a.npix_in << a.ck4_shift;
+
+    auto tile_origin = [&](int item, int& b, int& oy0, int& ox0) {
+        int t = (int)blockIdx.x + (SINGLE ? item : item / nst) * (int)gridDim.x;
+        const int tx = t % a.tiles_x; t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        b = t / a.tiles_y;
+        oy0 = ty * a.TH; ox0 = tx * a.TW;
+    };
+    auto prefetch = [&](int item, f32x4 (&v)[NV]) {      // item >= n_items: every lane reads the zero page
+        const bool live = item < n_items;
+        int b, oy0, ox0;
+        tile_origin(live ? item : 0, b, oy0, ox0);
+        const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
+        const int c0 = SINGLE ? 0 : (item % nst) * a.ck;
+        const float* srcb = a.src + (size_t)b * a.Hin * a.Win * a.src_cs;
+        int tq = tid; asm volatile("" : "+v"(tq));       // opaque: the per-slot addresses are recomputed per item, not kept in ~50 VGPRs
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int idx = u * 256 + tq;
+            const int pix = idx >> a.ck4_shift, q = idx & ck4m;
+            const int iy = (int)(((float)pix + 0.5f) * a.inv_TWin);
+            const int ix = pix - iy * a.TWin;
+            const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + 4 * q;
+            const bool inb = live && idx < total_f4 && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && c < a.cin4;
+            const float* gp = inb ? srcb + ((size_t)gy * a.Win + gx) * a.src_cs + c : a.zeros;
+            v[u] = *(const f32x4*)gp;
+        }
+    };
+    auto commit = [&](const f32x4 (&v)[NV]) {
+        int tq = tid; asm volatile("" : "+v"(tq));
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int idx = u * 256 + tq;
+            if (idx < total_f4) *(f32x4*)(lds + (idx >> a.ck4_shift) * a.ldp + 4 * (idx & ck4m)) = v[u];
+        }
+    };
+    int xoff[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        int p = (wp * PT + pt) * 16 + (lane & 15);
+        p = p < npix ? p : 0;
+        const int ly = (int)(((float)p + 0.5f) * a.inv_TW);
+        const int lx = p - ly * a.TW;
+        xoff[pt] = ((ly * STRIDE) * a.TWin + lx * STRIDE) * a.ldp + (lane >> 4) * 4;
+    }
+    const float* wbase[CT];
+    f32x4 bias4[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        wbase[ct] = a.wpk + (size_t)ctile * TAPS * a.cib * 256 + lane * 4;
+        bias4[ct] = *(const f32x4*)(a.bias + ctile * 16 + (lane >> 4) * 4);
+    }
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // K-loop state of the item whose weights are being fetched (set up by begin_item, consumed by the loop below)
+    const int wstep = a.cib * 256;
+    int n_it = 0, cib0 = 0;
+    int w_it = 0, w_kw = 0, w_kh = 0, w_kk = 0, w_off = 0;
+    f32x4 wf[WD][CT];
+    auto load_w = [&](f32x4* w) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(wbase[ct] + w_off);
+        if (w_it + 1 < n_it) {
+            ++w_it; ++w_kw; w_off += wstep;
+            if (w_kw == KS) {
+                w_kw = 0; ++w_kh;
+                if (w_kh == KS) { w_kh = 0; ++w_kk; w_off = (cib0 + w_kk) * 256; }
+            }
+        }
+    };
+    auto begin_item = [&](int item) {                       // cursor reset + the first WD-1 weight fragments
+        const int st = SINGLE ? 0 : item % nst;
+        const int c0 = st * a.ck;
+        const int rem = a.Cin - c0;
+        n_it = (((rem < a.ck ? rem : a.ck) + 15) >> 4) * TAPS;
+        cib0 = c0 >> 4;
+        w_it = 0; w_kw = 0; w_kh = 0; w_kk = 0; w_off = cib0 * 256;
+#pragma unroll
+        for (int j = 0; j < WD - 1; ++j) load_w(wf[j]);
+    };
+
+    f32x4 pv[NV];
+    prefetch(0, pv);
+    commit(pv);
+    __syncthreads();
+    begin_item(0);
+    prefetch(1, pv);
+    for (int item = 0; item < n_items; ++item) {
+        int x_it = 0, x_kw = 0, x_kh = 0, x_kk = 0, x_off = 0;
+        f32x4 xf[2][PT];
+        auto load_x = [&](f32x4* x) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) x[pt] = *(const f32x4*)__builtin_assume_aligned(lds + xoff[pt] + x_off, 16);
+            if (x_it + 1 < n_it) {
+                ++x_it; ++x_kw; x_off += a.ldp;
+                if (x_kw == KS) {
+                    x_kw = 0; ++x_kh; x_off += (a.TWin - KS) * a.ldp;
+                    if (x_kh == KS) { x_kh = 0; ++x_kk; x_off = x_kk * 16; }
+                }
+            }
+        };
+        auto mma = [&](const f32x4* w, const f32x4* x) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt)
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][s], x[pt][s], acc[ct][pt], 0, 0, 0);
+        };
+        load_x(xf[0]);
+        const int n_cur = n_it;
+        for (int it = 0; it < n_cur; it += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                load_w(wf[(j + WD - 1) % WD]);
+                load_x(xf[(j + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + j < n_cur) mma(wf[j % WD], xf[j & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                                   // every wave is done reading this item's LDS image
+        commit(pv);                                        // item + 1 (zeros after the last one)
+        const bool tile_done = SINGLE || (item % nst) == nst - 1;
+        begin_item(item + 1 < n_items ? item + 1 : item);  // next weights requested before the stores and the prefetch
+        if (tile_done) {
+            int b, oy0, ox0;
+            tile_origin(item, b, oy0, ox0);
+            conv_epilogue<STRIDE, PT, CT, WP>(a, acc, bias4, lane, wp, ct0, b, oy0, ox0, npix);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        prefetch(item + 2, pv);
+        __syncthreads();                                   // item + 1's LDS image is complete
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- v2
 // Same GEMM, same canonical accumulation order, different staging: a 5th wave is a pure LOADER.  It fills the next
 // stage's halo tile with LDS-DMA (global_load_lds_dwordx4: 1 KiB per instruction, no VGPR round trip) into the second
@@ -552,9 +721,10 @@ __global__ __launch_bounds__(256) void conv1x1_pipe_f32(ConvKArgs a) {
         const int ti = SINGLE ? item : item / nst;
         const int p0 = ((int)blockIdx.x + ti * (int)gridDim.x) * P;
         const int c0 = SINGLE ? 0 : (item - ti * nst) * a.ck;
+        int tq = tid; asm volatile("" : "+v"(tq));       // opaque: slot addresses recomputed per item instead of living in VGPRs
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
-            const int idx = u * 256 + tid;
+            const int idx = u * 256 + tq;
             const int pix = idx >> sh, q = idx & ck4m;
             const int p = p0 + pix, c = c0 + 4 * q;
             const bool inb = live && idx < tile_v && p < total && c < a.cin4;
@@ -563,9 +733,10 @@ __global__ __launch_bounds__(256) void conv1x1_pipe_f32(ConvKArgs a) {
         }
     };
     auto commit = [&](const f32x4 (&v)[NV]) {
+        int tq = tid; asm volatile("" : "+v"(tq));
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
-            const int idx = u * 256 + tid;
+            const int idx = u * 256 + tq;
             if (idx < tile_v) *(f32x4*)(lds + (idx >> sh) * a.ldp + 4 * (idx & ck4m)) = v[u];
         }
     };
@@ -729,6 +900,23 @@ KernelFn pick_stream(int CT, int PT) {
     return nullptr;
 }
 
+template <int KS, int STRIDE, bool SINGLE>
+KernelFn pick_v5_s(int CT, int WP) {
+#define MI355_CASE5(ct, wp) if (CT == ct && WP == wp) return &conv_igemm_f32_v5<KS, STRIDE, 4, ct, wp, SINGLE>;
+    MI355_CASE5(1, 4) MI355_CASE5(2, 4) MI355_CASE5(3, 4) MI355_CASE5(4, 4)
+    MI355_CASE5(1, 2) MI355_CASE5(2, 2) MI355_CASE5(3, 2) MI355_CASE5(4, 2)
+    MI355_CASE5(1, 1) MI355_CASE5(2, 1) MI355_CASE5(3, 1) MI355_CASE5(4, 1)
+#undef MI355_CASE5
+    return nullptr;
+}
+
+KernelFn pick_v5(int ks, int stride, int CT, int WP, bool single) {
+    if (ks != 3) return nullptr;
+    if (stride == 1) return single ? pick_v5_s<3, 1, true>(CT, WP) : pick_v5_s<3, 1, false>(CT, WP);
+    if (stride == 2) return single ? pick_v5_s<3, 2, true>(CT, WP) : pick_v5_s<3, 2, false>(CT, WP);
+    return nullptr;
+}
+
 template <bool SINGLE, int NKK>
 KernelFn pick_pipe_s(int CT, int WP) {
 #define MI355_CASE4(ct, wp) if (CT == ct && WP == wp) return &conv1x1_pipe_f32<4, ct, wp, SINGLE, NKK>;
@@ -807,6 +995,15 @@ std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, i
                 }
                 if (best.cost < 1e30) {
                     out.push_back(best);
+                    {   // v5: the same tile, persistent + prefetched (the halo chunk must fit 8 float4 registers per thread)
+                        static const int use_v5 = env_int("MI355_CONV_V5", 0);   // measured: loses to v1 (3 vs 5 waves/SIMD); opt-in, tested
+                        const int THin5 = (best.TH - 1) * stride + ks, TWin5 = (best.TW - 1) * stride + ks;
+                        if (use_v5 && allow_v2 && !half && ks == 3 && CT <= 4 && PTsel == 0 && THin5 * TWin5 * ck / 4 <= 2048) {
+                            Plan v5 = best;
+                            v5.version = 5; v5.cost = best.cost * 0.9;
+                            out.push_back(v5);
+                        }
+                    }
                     // v2 variant of the same tile: dense double-buffered LDS image filled by a DMA loader wave
                     const int stages = (cin16 + ck - 1) / ck;
                     const int THin = (best.TH - 1) * stride + ks, TWin = (best.TW - 1) * stride + ks;
@@ -896,7 +1093,8 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     KernelFn fn = half ? (p.version == 4 ? (KernelFn)pick_conv_pipe_f16(p.CT, p.WP, (c.Cin + 1) / 2 <= p.ck, p.ck > 64)
                                          : (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.version == 3 ? p.buf_floats : p.PT))
                        : (p.version == 3 ? pick_stream(p.CT, p.buf_floats)
-                          : p.version == 4 ? pick_pipe(p.CT, p.WP, c.Cin <= p.ck, p.ck) : pick_kernel(c.k, c.stride, p.CT, p.WP, p.version));
+                          : p.version == 4 ? pick_pipe(p.CT, p.WP, c.Cin <= p.ck, p.ck)
+                          : p.version == 5 ? pick_v5(c.k, c.stride, p.CT, p.WP, c.Cin <= p.ck) : pick_kernel(c.k, c.stride, p.CT, p.WP, p.version));
     if (!fn) return "conv: no kernel instance";
     a.zeros = c.zeros; a.lds_buf_floats = p.buf_floats;
     if (half && p.version == 4) a.lds_buf_floats = 0;
@@ -914,9 +1112,15 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     out->fn = (const void*)fn;
     a.n_tiles_total = (int)((long)B * a.tiles_x * a.tiles_y);
     out->grid_x = (unsigned)a.n_tiles_total;
-    if (p.version == 4) {      // persistent: a few resident blocks per CU, each walks tiles blockIdx.x, + gridDim.x, ...
+    if (p.version == 4 || p.version == 5) {
+        // persistent: exactly as many blocks as stay resident (asked of the runtime: registers, LDS), each walks tiles
+        // blockIdx.x, + gridDim.x, ...; blocks that had to queue behind others would leave CUs half empty at the end
         const int gy = std::max(1, (a.n_ctiles + p.CT * (4 / p.WP) - 1) / (p.CT * (4 / p.WP)));
-        const int per_cu = std::max(1, std::min(4, (int)((size_t)(160 * 1024) / std::max<size_t>(p.lds, 1))));
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, 256, p.lds) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            per_cu = std::max(1, std::min(3, (int)((size_t)(160 * 1024) / std::max<size_t>(p.lds, 1))));
+        }
         out->grid_x = std::min(out->grid_x, (unsigned)std::max(1, 256 * per_cu / gy));
     }
     if (p.version == 2) {      // persistent: as many blocks as stay resident (LDS-limited), each loops over tiles

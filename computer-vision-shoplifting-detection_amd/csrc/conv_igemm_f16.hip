@@ -355,9 +355,10 @@ __global__ __launch_bounds__(256) void conv1x1_pipe_f16(ConvKArgs a) {
         const int ti = SINGLE ? item : item / nst;
         const int p0 = ((int)blockIdx.x + ti * (int)gridDim.x) * P;
         const int c0 = SINGLE ? 0 : (item - ti * nst) * a.ck;
+        int tq = tid; asm volatile("" : "+v"(tq));       // opaque: slot addresses recomputed per item instead of living in VGPRs
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
-            const int idx = u * 256 + tid;
+            const int idx = u * 256 + tq;
             const int pix = idx >> sh, q = idx & ck8m;
             const int p = p0 + pix, c = c0 + 8 * q;
             const bool inb = live && idx < tile_v && p < total && c < a.cin4;
@@ -366,9 +367,10 @@ __global__ __launch_bounds__(256) void conv1x1_pipe_f16(ConvKArgs a) {
         }
     };
     auto commit = [&](const f16x8 (&v)[NV]) {
+        int tq = tid; asm volatile("" : "+v"(tq));
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
-            const int idx = u * 256 + tid;
+            const int idx = u * 256 + tq;
             if (idx < tile_v) *(f16x8*)(lds_h + (idx >> sh) * a.ldp + 8 * (idx & ck8m)) = v[u];
         }
     };

@@ -442,7 +442,7 @@ static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, c
                     l.a.n_tiles_total = (int)((long)nb * l.a.tiles_x * l.a.tiles_y);
                 }
                 // v1: one block per tile; v2 (persistent): keep the planned grid unless fewer tiles exist
-                l.grid_x = (l.version == 2 || l.version == 4) ? std::min(l.grid_x, (unsigned)l.a.n_tiles_total) : (unsigned)l.a.n_tiles_total;
+                l.grid_x = (l.version == 2 || l.version == 4 || l.version == 5) ? std::min(l.grid_x, (unsigned)l.a.n_tiles_total) : (unsigned)l.a.n_tiles_total;
             }
             if (pf.begin(K_CONV)) return fail(MI355_EHIP, "event");
             KCHK(run_conv(l, h->stream));
