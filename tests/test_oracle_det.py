@@ -67,3 +67,36 @@ def test_det_vs_torch_oracle_640_statistics():
 @pytest.mark.parametrize("tag", ["lb_30x40", "lb_48x48", "lb_100x37"])
 def test_letterbox_golden(tag):
     np.testing.assert_array_equal(O.letterbox(G[f"{tag}/in"], (64, 64)), G[f"{tag}/out"])
+
+
+def test_sigmoid_window_used_by_the_decode_kernel():
+    """decode_kernel_v2 evaluates the canonical sigmoid only for class logits >= thr(max logit) (post_kernels.hip) and
+    must still return the reference's (max score, FIRST argmax).  Property behind it, on the canonical det_expf:
+    logits outside the window never reach the maximum's score; then the windowed scan equals the full scan."""
+    from oracle import det
+    rng = np.random.default_rng(5)
+
+    def sig(v):
+        v = np.asarray(v, dtype=np.float32)
+        return (np.float32(1.0) / (np.float32(1.0) + det.expf(-v))).astype(np.float32)
+
+    def thr(m):
+        return np.float32(10.9) if m > 11 else (np.float32(-np.inf) if m < -80 else np.float32(m - np.float32(0.01)))
+
+    # strictness just outside the window, over the whole non-saturated range
+    m = rng.uniform(-80, 11, 200000).astype(np.float32)
+    gap = (np.float32(0.01) + rng.uniform(0, 0.02, m.size).astype(np.float32))
+    lo = (m - gap).astype(np.float32)
+    lo = np.minimum(lo, np.nextafter((m - np.float32(0.01)).astype(np.float32), np.float32(-np.inf)))   # strictly below the window
+    assert (sig(lo) < sig(m)).all()
+    # windowed scan == full scan on logit vectors of every flavour (ties, saturation, underflow)
+    for scale, shift in [(1, 0), (3, -4), (0.01, 5), (6, 10), (10, -90), (0.001, 0), (20, 0)]:
+        L = (rng.standard_normal((3000, 80)) * scale + shift).astype(np.float32)
+        L[::7, 5] = L[::7, 40]                                 # exact ties
+        S = sig(L)
+        want_best, want_idx = S.max(1), S.argmax(1)            # argmax = first occurrence, like the reference's `>` scan
+        for i in range(len(L)):
+            t = thr(L[i].max())
+            cand = np.nonzero(L[i] >= t)[0]
+            s = S[i, cand]
+            assert s.max() == want_best[i] and cand[s.argmax()] == want_idx[i]
