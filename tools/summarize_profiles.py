@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 from cvsd_amd.graph import build_program, parse_model_name
 pg = build_program(*parse_model_name(model))
 n_conv = sum(1 for c in pg.convs if c.cin != 3)
-is_conv = lambda name: "conv_igemm" in name or "conv1x1_stream" in name
+is_conv = lambda name: "conv_igemm" in name or "conv1x1_" in name
 
 
 def conv_sum(pat, counter, passes=6):
