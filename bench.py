@@ -163,7 +163,7 @@ def main() -> None:
                                f"predict conf=0.25 iou=0.7 max_det=300 (letterbox+stem, conv graph, decode, NMS, rows to host)",
                    "global_batch": B * world, "params": params, "gflop_per_frame": round(gflops * scale, 3),
                    "parallelism": f"frame-sharded dp{world}"},
-        "roofline": {"bound": "mfma", "kernel": ("conv_igemm_f16" if args.half else "conv_igemm_f32") + " (all instances)",
+        "roofline": {"bound": "mfma", "kernel": ("conv_igemm_f16 + conv1x1_pipe_f16" if args.half else "conv_igemm_f32 + conv1x1_pipe_f32 + conv1x1_stream_f32") + " (every conv launch of a step)",
                      "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
                      "launches_per_step": launches // PROF_STEPS,

@@ -191,3 +191,23 @@ def test_config5_yolov8m_1280_half():
         assert err[0] <= 1.5 * noise[0] + 1e-6, (group, "median", err, noise)
         assert err[1] <= 1.5 * noise[1] + 1e-5, (group, "p99", err, noise)
         assert err[2] <= 4.0 * noise[2] + 1e-4, (group, "max", err, noise)
+
+
+def test_reference_call_sites_with_half(v8n_pose):
+    """the reference's own calls on the half engine: .track(frame, persist=True, classes=[0]) (model.py:38) and
+    model(frame).keypoints on a UCF-Crime-shaped frame (resize + letterbox path)"""
+    from tools import synth
+    m = _half_model("yolov8n-pose", v8n_pose)
+    frames = synth.synthetic_frames(3, 240, 320, seed=8)
+    seen = 0
+    for f in frames:
+        res = m.track(f, persist=True, show=False, classes=[0], verbose=False)[0]
+        assert res.orig_shape == (240, 320)
+        if res.boxes.is_track:
+            seen += 1
+            assert res.boxes.data.shape[1] == 7 and float(res.boxes[0].id) >= 1
+            xywhn = res.boxes.xywhn.numpy()
+            assert (xywhn >= 0).all() and (xywhn <= 1).all()
+    assert seen >= 1
+    r = m(frames[0], conf=0.1)[0]
+    assert r.keypoints.data.shape[1:] == (17, 3) and len(r.keypoints) == len(r.boxes)
