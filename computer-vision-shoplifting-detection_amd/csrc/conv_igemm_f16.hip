@@ -149,7 +149,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(ConvKArgs a) {
     const int ck8m = (a.ck >> 3) - 1;
     const int total_v = a.npix_in << a.ck4_shift;          // 16-byte slots of one staged chunk
 
-    const int exp_flags = a.lds_buf_floats;      // diagnostics only (MI355_F16_EXP): 1 skip staging, 2 weights not re-fetched, 4 no stores
+    // What-if diagnostics: built only with -DMI355_F16_DIAG=1, then MI355_F16_EXP selects
+    // 1 skip staging, 2 weights not re-fetched, 4 no stores, 8 no weight loads in the K loop, 16 no LDS fragment reads
+#ifdef MI355_F16_DIAG
+    const int exp_flags = a.lds_buf_floats;
+#else
+    constexpr int exp_flags = 0;
+#endif
     for (int c0 = 0; c0 < a.Cin; c0 += a.ck) {
         if (c0) __syncthreads();
         // stage the halo tile, channels [c0, c0+ck): 8 loads per thread in flight, zero page outside the image / beyond Cin
@@ -223,7 +229,6 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(ConvKArgs a) {
                 const int xk = opaque(kb * 32), xkn = opaque(kn * 32);
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) {
-                    constexpr int dummy = 0; (void)dummy;
                     const int tw = (t + 2) % TAPS, tx = (t + 1) % TAPS;
                     load_w(wf[(t + 2) % R], opaque(((t + 2) >= TAPS ? wkn : wk) + wt[tw]));
                     load_x(xf[(t + 1) % R], opaque(((t + 1) >= TAPS ? xkn : xk) + xt[tx]));
