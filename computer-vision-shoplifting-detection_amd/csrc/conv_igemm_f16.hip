@@ -12,6 +12,7 @@
 // the instruction assigns k to lanes, because both operands use the same assignment.
 #include "common.h"
 #include "detmath.h"
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -243,7 +244,19 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(ConvKArgs a) {
             load_w(wf[0], (cib0 + koff(0)) * 512);
             load_w(wf[1], (cib0 + koff(1)) * 512);
             load_x(xf[0], 0);
-            for (int kb0 = 0; kb0 < nkk; kb0 += R) {
+            int kb0 = 0;
+            for (; kb0 + R <= nkk; kb0 += R) {               // whole trips: no guard, no branch inside
+#pragma unroll
+                for (int t = 0; t < R; ++t) {
+                    const int kw = koff(kb0 + t + 2), kx = koff(kb0 + t + 1);
+                    load_w(wf[(t + 2) % R], opaque((cib0 + ((exp_flags & 2) ? 0 : kw)) * 512));
+                    load_x(xf[(t + 1) % R], opaque(kx * 32));
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(wf[t % R], xf[t % R]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (kb0 < nkk) {                                  // ragged tail trip
 #pragma unroll
                 for (int t = 0; t < R; ++t) {
                     const int kw = koff(kb0 + t + 2), kx = koff(kb0 + t + 1);
@@ -421,21 +434,26 @@ __global__ __launch_bounds__(256) void conv1x1_pipe_f16(ConvKArgs a) {
         f16x8 xf[2][PT];
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) xf[0][pt] = *(const f16x8*)__builtin_assume_aligned(lds_h + xoff[pt], 16);
+        // a taken branch costs this loop ~10 % of a step, so full chunks (all but possibly the last one of a tile) run a
+        // copy of the loop without the per-k-block guard
+        auto kloop = [&](auto guarded) {
 #pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
-            const int kn = (kk + 1 < nkk ? kk + 1 : nkk - 1) * 32;
+            for (int kk = 0; kk < NKK; ++kk) {
+                const int kn = decltype(guarded)::value ? (kk + 1 < nkk ? kk + 1 : nkk - 1) * 32 : (kk + 1 < NKK ? kk + 1 : NKK - 1) * 32;
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) xf[(kk + 1) & 1][pt] = *(const f16x8*)__builtin_assume_aligned(lds_h + xoff[pt] + kn, 16);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kk < nkk) {
+                for (int pt = 0; pt < PT; ++pt) xf[(kk + 1) & 1][pt] = *(const f16x8*)__builtin_assume_aligned(lds_h + xoff[pt] + kn, 16);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!decltype(guarded)::value || kk < nkk) {
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
+                    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                    for (int pt = 0; pt < PT; ++pt)
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[kk][ct], xf[kk & 1][pt], acc[ct][pt], 0, 0, 0);
+                        for (int pt = 0; pt < PT; ++pt)
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[kk][ct], xf[kk & 1][pt], acc[ct][pt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        if (nkk == NKK) kloop(std::false_type{}); else kloop(std::true_type{});
         __syncthreads();                                   // every wave is done reading this item's LDS image
         commit(pv);                                        // item + 1 (zeros after the last one)
         load_w(item + 1 < n_items ? item + 1 : item);      // requested before the stores and the next prefetch
