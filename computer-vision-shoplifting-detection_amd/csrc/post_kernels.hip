@@ -9,6 +9,7 @@
 #include "common.h"
 #include "../../include/mi355_yolo.h"
 #include "detmath.h"
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -267,6 +268,135 @@ __global__ __launch_bounds__(DEC_T) void decode_kernel_v2(DecodeArgs a, int ps) 
         for (int c = sub; c < nk; c += 16) out0[(size_t)r * no + 4 + a.nc + c] = tile[r * pw + c];
 }
 
+// v3 ("quad"): FOUR lanes per anchor and no LDS.  Lane s of a quad owns DFL side s (its 16 logits are 64 contiguous bytes:
+// four 16-byte loads), a quarter of the class logits and a quarter of the keypoint values; the four distances, the class
+// maximum and the (score, first argmax) pair are combined with wave shuffles.  The LDS kernels above stage 336 bytes per
+// anchor and so run at 1.5 waves per SIMD; this one is bound by its loads.  Per-element arithmetic and every summation
+// order are unchanged (a DFL side is still evaluated sequentially by one lane): same bits.
+template <bool FULL>
+__global__ __launch_bounds__(256) void decode_kernel_quad(DecodeArgs a) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)a.B * a.A;
+    const long ag0 = gid >> 2;
+    const int s = (int)(gid & 3);
+    const bool live = ag0 < total;
+    const long ag = live ? ag0 : total - 1;                 // dead quads shadow the last anchor (shuffles need all lanes), stores are guarded
+    const int b = (int)(ag / a.A), an = (int)(ag - (long)b * a.A);
+    int l = 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        if (j < a.n_levels && an >= a.lv[j].anchor0) l = j;
+    const HeadLevelArgs lv = a.lv[l];
+    const int li = an - lv.anchor0;
+    const int y = li / lv.W, x = li - y * lv.W;
+    const float ax = (float)x + 0.5f, ay = (float)y + 0.5f, st = (float)lv.stride;
+    const float* src = lv.buf + ((size_t)b * lv.H * lv.W + li) * lv.cs;
+    const int nk = a.nkpt * a.kdim, no = 4 + a.nc + nk;
+    float* out = a.pred + (size_t)ag * no;
+    const int lane = threadIdx.x & 63, qbase = lane & ~3;
+
+    // ---- box: side s
+    float d;
+    {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 q4 = *(const float4*)(src + lv.box_off + 16 * s + 4 * j);
+            v[4 * j] = q4.x; v[4 * j + 1] = q4.y; v[4 * j + 2] = q4.z; v[4 * j + 3] = q4.w;
+        }
+        float m = v[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) m = fmaxf(m, v[j]);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { v[j] = det_expf(v[j] - m); sum += v[j]; }
+        d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) d += (v[j] / sum) * (float)j;
+    }
+    const float d0 = __shfl(d, qbase), d1 = __shfl(d, qbase + 1), d2 = __shfl(d, qbase + 2), d3 = __shfl(d, qbase + 3);
+    if (live && s == 0) {
+        const float x1 = ax - d0, y1 = ay - d1, x2 = ax + d2, y2 = ay + d3;
+        float4 o;
+        o.x = ((x1 + x2) / 2.0f) * st;
+        o.y = ((y1 + y2) / 2.0f) * st;
+        o.z = (x2 - x1) * st;
+        o.w = (y2 - y1) * st;
+        if ((no & 3) == 0) *(float4*)out = o;
+        else { out[0] = o.x; out[1] = o.y; out[2] = o.z; out[3] = o.w; }
+    }
+    // ---- classes: lane s owns classes c = s, s + 4, s + 8, ... (or whole float4 groups, below)
+    {
+        const float* cl = src + lv.cls_off;
+        // 16-byte form when the class slice allows it: lane s owns the float4 groups s, s + 4, ... (classes 4q .. 4q+3)
+        const bool vec = (a.nc & 3) == 0 && (lv.cls_off & 3) == 0;
+        const int ncq = a.nc >> 2;
+        float thr = -__builtin_huge_valf();
+        if (!FULL) {            // see decode_kernel_v2: only logits within a hair of the maximum can hold the best score
+            float m = -__builtin_huge_valf();
+            if (vec) {
+                for (int q = s; q < ncq; q += 4) {
+                    const float4 v = *(const float4*)(cl + 4 * q);
+                    m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+                }
+            } else {
+                for (int c = s; c < a.nc; c += 4) m = fmaxf(m, cl[c]);
+            }
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fmaxf(m, __shfl_xor(m, 2));
+            thr = m > 11.0f ? 10.9f : (m < -80.0f ? -__builtin_huge_valf() : m - 0.01f);
+        }
+        float best = -1.f; int bi = 0x7fffffff;
+        if (vec) {
+            for (int q = s; q < ncq; q += 4) {
+                const float4 v = *(const float4*)(cl + 4 * q);
+                float lg[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (FULL || lg[j] >= thr) {
+                        lg[j] = det_sigmoid(lg[j]);
+                        if (lg[j] > best) { best = lg[j]; bi = 4 * q + j; }
+                    }
+                }
+                if (FULL && live) {
+                    if ((no & 3) == 0) *(float4*)(out + 4 + 4 * q) = make_float4(lg[0], lg[1], lg[2], lg[3]);
+                    else { out[4 + 4 * q] = lg[0]; out[5 + 4 * q] = lg[1]; out[6 + 4 * q] = lg[2]; out[7 + 4 * q] = lg[3]; }
+                }
+            }
+        } else {
+            for (int c = s; c < a.nc; c += 4) {
+                const float lg = cl[c];
+                if (FULL || lg >= thr) {
+                    const float sc = det_sigmoid(lg);
+                    if (FULL && live) out[4 + c] = sc;
+                    if (sc > best) { best = sc; bi = c; }
+                }
+            }
+        }
+        // (max score, FIRST class that attains it) over the quad == the reference's ascending `>` scan
+#pragma unroll
+        for (int off = 1; off <= 2; off <<= 1) {
+            const float ob = __shfl_xor(best, off);
+            const int oi = __shfl_xor(bi, off);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (bi == 0x7fffffff) bi = 0;                        // no score beat -1 (all NaN): the reference leaves class 0
+        if (live && s == 0) a.best[ag] = make_float2(best, (float)bi);
+    }
+    // ---- keypoints: element e = s, s + 4, ... of the nk values; e = k * kdim + component
+    if (nk) {
+        const float* kp = src + lv.kpt_off;
+        for (int e = s; e < nk; e += 4) {
+            const int k = e / a.kdim, comp = e - k * a.kdim;
+            float v = kp[e];
+            if (comp == 0) v = (v * 2.0f + (ax - 0.5f)) * st;
+            else if (comp == 1) v = (v * 2.0f + (ay - 0.5f)) * st;
+            else if (a.kdim == 3) v = det_sigmoid(v);
+            if (live) out[4 + a.nc + e] = v;
+        }
+    }
+}
+
 const char* launch_decode(const DecodeArgs& a0, bool full, hipStream_t st) {
     DecodeArgs a = a0;
     const int nk = a.nkpt * a.kdim;
@@ -274,6 +404,19 @@ const char* launch_decode(const DecodeArgs& a0, bool full, hipStream_t st) {
     for (int l = 0; l < a.n_levels; ++l) { a.tile0[l] = t; t += (a.lv[l].H * a.lv[l].W + DEC_T - 1) / DEC_T; }
     a.tiles_per_image = t;
     const dim3 grid((unsigned)(a.B * t));
+    {   // quad kernel: needs 16-byte aligned box logits only
+        static const bool use_quad = []() { const char* e = getenv("MI355_DECODE_QUAD"); return e ? atoi(e) != 0 : true; }();
+        bool ok = use_quad;
+        for (int l = 0; l < a.n_levels; ++l) ok = ok && (a.lv[l].cs & 3) == 0 && (a.lv[l].box_off & 3) == 0;
+        if (ok) {
+            const long lanes = (long)a.B * a.A * 4;
+            const dim3 g((unsigned)((lanes + 255) / 256));
+            if (full) hipLaunchKernelGGL(decode_kernel_quad<true>, g, dim3(256), 0, st, a);
+            else      hipLaunchKernelGGL(decode_kernel_quad<false>, g, dim3(256), 0, st, a);
+            hipError_t e3 = hipGetLastError();
+            return e3 == hipSuccess ? nullptr : hipGetErrorString(e3);
+        }
+    }
     bool aligned = ((4 + a.nc + nk) & 3) == 0;
     for (int l = 0; l < a.n_levels; ++l)
         aligned = aligned && (a.lv[l].cs & 3) == 0 && (a.lv[l].box_off & 3) == 0 && (a.lv[l].cls_off & 3) == 0 && (a.lv[l].kpt_off & 3) == 0;
