@@ -33,8 +33,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="yolov8n")
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
-    ap.add_argument("--chunk", type=int, default=256, help="engine batch_chunk: frames per pass through the net")
+    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
+    ap.add_argument("--chunk", type=int, default=512, help="engine batch_chunk: frames per pass through the net")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-frames", action="store_true",
@@ -151,7 +151,7 @@ def main() -> None:
     # process); only quoted when it was collected on this exact workload
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
-    if os.path.exists(tpath) and args.model == "yolov8n" and args.size == 640 and B == 256 and args.chunk == 256 and not args.half:
+    if os.path.exists(tpath) and args.model == "yolov8n" and args.size == 640 and B == 512 and args.chunk == 512 and not args.half:
         with open(tpath) as f:
             traffic = json.load(f)["hbm_bytes_per_launch_avg"]
     peak = F16_PEAK_TFLOPS if args.half else FP32_PEAK_TFLOPS

@@ -9,7 +9,7 @@ model = sys.argv[3] if len(sys.argv) > 3 else "yolov8n"
 size = int(sys.argv[4]) if len(sys.argv) > 4 else 640
 half = len(sys.argv) > 5 and sys.argv[5] == "half"
 es = 2 if half else 4
-g = lambda pat: glob.glob(os.path.join(ROOT, "gpurun_out", pat))[0]
+g = lambda pat: max(glob.glob(os.path.join(ROOT, "gpurun_out", pat)), key=os.path.getmtime)   # newest run if stale ones linger
 shutil.copy(g(f"{tag}_trace/*/*kernel_stats.csv"), os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
 with open(os.path.join(ROOT, "profiles", f"{tag}_bench_under_rocprof.json"), "w") as f:
     f.write([l for l in open(os.path.join(ROOT, "gpurun_out", f"{tag}_trace.log")) if l.startswith('{"metric')][-1])
