@@ -147,44 +147,45 @@ __global__ __launch_bounds__(256) void stem_mfma_u8(StemArgs a) {
     // ---- input tile: u8 -> float through the table, 0 outside the image (fma(0, w, acc) == acc: same as skipping) ----
     const int nd = (trow + 6) >> 2;                             // aligned dwords that cover a tile row at any alignment
     const int n_items = TIN * nd;
-    // batches of 4 dwords per thread, all loads issued before the first table lookup (one memory latency per batch)
+    // batches of 4 dwords per thread, all loads issued before the first table lookup (one memory latency per batch).
+    // Byte positions are 32-bit offsets from the frame base (`mis` = its misalignment), so the address math is int32.
+    const int mis = (int)((uintptr_t)img & 3);
+    const int wrow = a.W * 3;
     for (int base_item = 0; base_item < n_items; base_item += 4 * 256) {
         unsigned bytes[4];
-        long long dd[4], tlo[4], rlo[4];
-        int riy[4];
+        int dd[4], tlo[4], rlo[4], riy[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int item = base_item + u * 256 + tid;
             const int iy = item / nd, j = item - iy * nd;
             const int gy = iy0 + iy;
             const bool rowin = item < n_items && (unsigned)gy < (unsigned)a.H;
-            const uint8_t* rowp = img + (size_t)(rowin ? gy : 0) * a.W * 3;
-            const long long row_lo = (long long)(uintptr_t)rowp, row_hi = row_lo + (long long)a.W * 3;
-            const long long tile_lo = row_lo + (long long)ix0 * 3;
-            const long long d = (tile_lo & ~3ll) + 4 * j;      // absolute address of this aligned dword
+            const int row_lo = (rowin ? gy : 0) * wrow, row_hi = row_lo + wrow;
+            const int tile_lo = row_lo + ix0 * 3;
+            const int d = ((tile_lo + mis) & ~3) - mis + 4 * j;   // offset of this dword; img + d is 4-byte aligned
             unsigned v = 0;
             if (rowin) {
                 if (d >= row_lo && d + 4 <= row_hi) {
-                    v = *(const unsigned*)(uintptr_t)d;
+                    v = *(const unsigned*)(img + d);
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (d + q >= row_lo && d + q < row_hi) v |= (unsigned)(*(const uint8_t*)(uintptr_t)(d + q)) << (8 * q);
+                        if (d + q >= row_lo && d + q < row_hi) v |= (unsigned)img[d + q] << (8 * q);
                 }
             }
             bytes[u] = v; dd[u] = d; tlo[u] = tile_lo; riy[u] = item < n_items ? iy : -1;
-            rlo[u] = rowin ? row_lo : (1ll << 62);             // rows outside the image: no byte is "in the image"
+            rlo[u] = rowin ? row_lo : 0x3fffffff;              // rows outside the image: no byte is "in the image"
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (riy[u] < 0) continue;
-            const long long row_hi = rlo[u] + (long long)a.W * 3;
+            const int row_hi = rlo[u] + wrow;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const long long ab = dd[u] + q, rel = ab - tlo[u];
+                const int ab = dd[u] + q, rel = ab - tlo[u];
                 if (rel >= 0 && rel < trow) {
                     const bool inimg = ab >= rlo[u] && ab < row_hi;
-                    tin[riy[u] * trow + (int)rel] = inimg ? lut[(bytes[u] >> (8 * q)) & 255u] : 0.f;
+                    tin[riy[u] * trow + rel] = inimg ? lut[(bytes[u] >> (8 * q)) & 255u] : 0.f;
                 }
             }
         }
