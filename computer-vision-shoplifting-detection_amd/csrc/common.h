@@ -23,6 +23,10 @@ struct ConvArgs {
     // half=True path (conv_igemm_f16.hip): dtype 1 = src / res / wpk hold fp16 (pack_conv_weights_f16), strides count halfs;
     // dst holds fp16 too unless out_f32 (the head's final convs).  The pointers keep their float* type; only bytes matter.
     int dtype = 0, out_f32 = 0;
+    // Fused nearest-2x upsample on the read side (pointwise convs, v4 kernels only): input channels [0, up_c) come from
+    // `src2`, a map of half the resolution (pixel (y/2, x/2), stride src2_cs), channels >= up_c from `src` as usual --
+    // torch.nn.Upsample + Concat + Conv1x1 of the neck without the upsampled tensor ever being written.
+    const float* src2 = nullptr; int src2_cs = 0, up_c = 0;
 };
 // number of floats pack_conv_weights writes: ceil(cout/16) * k*k * ceil(cin/16) * 256
 size_t packed_weight_floats(int cout, int cin, int k);
@@ -50,6 +54,7 @@ struct ConvKArgs {
     int pad, act;
     const float* zeros;        // >= 16 bytes of zeros (source of out-of-image / beyond-Cin slots of the v2 LDS-DMA loader)
     int out_f32;               // fp16 kernels: destination (and residual) hold fp32
+    const float* src2; int src2_cs, up_c, up_W, up_H;   // fused upsample-on-read (v4): full-resolution W, H of the conv input
     int lds_buf_floats;        // v2: floats per LDS stage buffer
     int n_tiles_total;         // B * tiles_x * tiles_y (v2 blocks loop over tiles)
     unsigned long long* debug; // diagnostics: per-wave phase stamps (6 words per wave), nullptr in product launches

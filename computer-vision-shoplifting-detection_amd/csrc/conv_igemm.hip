@@ -721,6 +721,9 @@ __global__ __launch_bounds__(256) void conv1x1_pipe_f32(ConvKArgs a) {
         const int ti = SINGLE ? item : item / nst;
         const int p0 = ((int)blockIdx.x + ti * (int)gridDim.x) * P;
         const int c0 = SINGLE ? 0 : (item - ti * nst) * a.ck;
+        // fused upsample: (image, row, column) of the tile's first pixel, once per item (uniform)
+        int ub = 0, uy = 0, ux = 0;
+        if (a.up_c) { const int hw = a.up_W * a.up_H; ub = p0 / hw; const int r = p0 - ub * hw; uy = r / a.up_W; ux = r - uy * a.up_W; }
         int tq = tid; asm volatile("" : "+v"(tq));       // opaque: slot addresses recomputed per item instead of living in VGPRs
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
@@ -728,7 +731,16 @@ __global__ __launch_bounds__(256) void conv1x1_pipe_f32(ConvKArgs a) {
             const int pix = idx >> sh, q = idx & ck4m;
             const int p = p0 + pix, c = c0 + 4 * q;
             const bool inb = live && idx < tile_v && p < total && c < a.cin4;
-            const float* src = inb ? a.src + (size_t)p * a.src_cs + c : a.zeros;
+            const float* src = a.src + (size_t)p * a.src_cs + c;
+            if (c < a.up_c) {                            // channels of the upsampled operand: read pixel (y/2, x/2) of the half-size map
+                const int xx = ux + pix;                 // < W + tile: the quotient is tiny, the float form is exact
+                const int wr = (int)(((float)xx + 0.5f) * a.inv_TW);        // inv_TW = 1 / up_W for these launches
+                const int x = xx - wr * a.up_W, yy = uy + wr;
+                const int hr = (int)(((float)yy + 0.5f) * a.inv_TWin);      // inv_TWin = 1 / up_H; a tile may span several small images
+                const int y = yy - hr * a.up_H, b = ub + hr;
+                src = a.src2 + (((size_t)b * (a.up_H >> 1) + (y >> 1)) * (a.up_W >> 1) + (x >> 1)) * a.src2_cs + c;
+            }
+            if (!inb) src = a.zeros;
             v[u] = *(const f32x4*)src;
         }
     };
@@ -1084,6 +1096,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     a.cib = half ? (c.Cin + 31) / 32 : (c.Cin + 15) / 16; a.n_ctiles = (c.Cout + 15) / 16;
     a.cin4 = half ? round_up(c.Cin, 8) : round_up(c.Cin, 4);       // channels covered by whole 16-byte vectors
     a.out_f32 = c.out_f32;
+    a.src2 = c.src2; a.src2_cs = c.src2_cs; a.up_c = c.src2 ? c.up_c : 0; a.up_W = c.Win; a.up_H = c.Hin;
     int B = c.B;
     if (c.k == 1) {   // pointwise: flatten batch and space into one row of pixels
         a.Hin = 1; a.Win = c.B * c.Hin * c.Win; a.Hout = 1; a.Wout = a.Win; B = 1;
@@ -1105,6 +1118,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     const int THin = (p.TH - 1) * c.stride + c.k;
     a.npix_in = a.TWin * THin;
     a.inv_TW = 1.0f / (float)p.TW; a.inv_TWin = 1.0f / (float)a.TWin;
+    if (p.version == 4 && a.up_c) { a.inv_TW = 1.0f / (float)c.Win; a.inv_TWin = 1.0f / (float)c.Hin; }   // v4 has no other use for them
     // plans count staged channels in 4-byte units; the fp16 kernels stage twice as many channels in the same bytes
     a.ck = half ? 2 * p.ck : p.ck; a.ldp = half ? a.ck + 8 : a.ck + 4;
     a.ck4_shift = (p.ck == 128 ? 5 : p.ck == 64 ? 4 : p.ck == 32 ? 3 : 2);
@@ -1153,10 +1167,12 @@ const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out
                                                     c.zeros != nullptr, half);
     if (plans.empty()) return "conv: no launch plan fits in LDS";
     for (const Plan& p : plans) {
+        if (c.src2 && p.version != 4) continue;       // upsample-on-read exists in the v4 kernels only
         ConvLaunch l{};
         if (const char* e = build_launch(c, p, &l)) return e;
         out->push_back(l);
     }
+    if (out->empty()) return "conv: no launch plan supports the fused upsample";
     return nullptr;
 }
 

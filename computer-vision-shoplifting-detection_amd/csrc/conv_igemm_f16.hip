@@ -373,6 +373,9 @@ __global__ __launch_bounds__(256) void conv1x1_pipe_f16(ConvKArgs a) {
         const int ti = SINGLE ? item : item / nst;
         const int p0 = ((int)blockIdx.x + ti * (int)gridDim.x) * P;
         const int c0 = SINGLE ? 0 : (item - ti * nst) * a.ck;
+        // fused upsample (see conv1x1_pipe_f32): (image, row, column) of the tile's first pixel, once per item
+        int ub = 0, uy = 0, ux = 0;
+        if (a.up_c) { const int hw = a.up_W * a.up_H; ub = p0 / hw; const int r = p0 - ub * hw; uy = r / a.up_W; ux = r - uy * a.up_W; }
         int tq = tid; asm volatile("" : "+v"(tq));       // opaque: slot addresses recomputed per item instead of living in VGPRs
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
@@ -380,7 +383,16 @@ __global__ __launch_bounds__(256) void conv1x1_pipe_f16(ConvKArgs a) {
             const int pix = idx >> sh, q = idx & ck8m;
             const int p = p0 + pix, c = c0 + 8 * q;
             const bool inb = live && idx < tile_v && p < total && c < a.cin4;
-            const _Float16* src = inb ? srcp + (size_t)p * a.src_cs + c : zeros;
+            const _Float16* src = srcp + (size_t)p * a.src_cs + c;
+            if (c < a.up_c) {
+                const int xx = ux + pix;
+                const int wr = (int)(((float)xx + 0.5f) * a.inv_TW);        // inv_TW = 1 / up_W for these launches
+                const int x = xx - wr * a.up_W, yy = uy + wr;
+                const int hr = (int)(((float)yy + 0.5f) * a.inv_TWin);      // inv_TWin = 1 / up_H; a tile may span several small images
+                const int y = yy - hr * a.up_H, b = ub + hr;
+                src = (const _Float16*)a.src2 + (((size_t)b * (a.up_H >> 1) + (y >> 1)) * (a.up_W >> 1) + (x >> 1)) * a.src2_cs + c;
+            }
+            if (!inb) src = zeros;
             v[u] = *(const f16x8*)src;
         }
     };

@@ -130,6 +130,10 @@ struct mi355_yolo {
     bool half = false;                  // opts.half: fp16 storage of activations / weights, fp32 arithmetic (conv_igemm_f16.hip)
     float* view(int buf, int choff) const { return (float*)((char*)dbuf[buf] + (size_t)choff * dbuf_es[buf]); }
     std::vector<ConvLaunch> plans;      // per op (valid for OP_CONV)
+    // Upsample -> Concat -> Conv1x1 of the neck, fused on the conv's read side: fuse_up[j] = index of the OP_UPSAMPLE op whose
+    // output only conv op j reads (or -1); fused_away[i] = that upsample is not launched.  Decided when the weights are
+    // loaded (program structure) and confirmed per shape (a v4 launch plan must exist), MI355_FUSE_UPSAMPLE=0 disables it.
+    std::vector<int> fuse_up; std::vector<char> fused_away;
     float* pred = nullptr; float2* best = nullptr; unsigned long long* keys = nullptr;
     int A = 0, Apow2 = 0;
     uint8_t* lbox = nullptr;            // letterboxed frames of one chunk (also the stable stem input of the graph path)
@@ -250,6 +254,30 @@ static int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
             HIPCHK(hipMemcpy(d.wpk, tmp.data(), pn * 4, hipMemcpyHostToDevice));
         }
     }
+    // fusable upsamples: written slice (D, o, C) read by exactly one later op, a pointwise conv whose input view starts at o
+    h->fuse_up.assign(h->ops.size(), -1); h->fused_away.assign(h->ops.size(), 0);
+    const char* fenv = getenv("MI355_FUSE_UPSAMPLE");
+    if (!fenv || atoi(fenv) != 0) {
+        for (size_t i = 0; i < h->ops.size(); ++i) {
+            const FileOp& u = h->ops[i];
+            if (u.type != OP_UPSAMPLE) continue;
+            int reader = -1, n_readers = 0;
+            for (size_t j = 0; j < h->ops.size(); ++j) {
+                const FileOp& o = h->ops[j];
+                if (j == i || o.type == OP_STEM) continue;
+                const bool reads = o.src_buf == u.dst_buf && o.src_choff < u.dst_choff + u.src_c && u.dst_choff < o.src_choff + o.src_c;
+                const bool reads_res = o.res_buf == u.dst_buf && o.res_choff < u.dst_choff + u.src_c && u.dst_choff < o.res_choff + o.dst_c;
+                if (reads || reads_res) { ++n_readers; reader = reads && !reads_res ? (int)j : -2; }
+            }
+            bool is_head = false;
+            for (const FileLevel& lv : h->levels) is_head |= ((int)lv.buf == u.dst_buf);
+            if (n_readers != 1 || reader < 0 || reader < (int)i || is_head) continue;
+            const FileOp& c = h->ops[reader];
+            if (c.type != OP_CONV || h->convs[c.conv].k != 1 || h->convs[c.conv].s != 1) continue;
+            if (c.src_choff != u.dst_choff || c.src_c < u.src_c) continue;      // the upsampled operand must lead the conv's input
+            h->fuse_up[reader] = (int)i; h->fused_away[i] = 1;
+        }
+    }
     float lut[256];
     for (int i = 0; i < 256; ++i) lut[i] = (float)i / 255.0f;     // im /= 255 (IEEE fp32 division)
     HIPCHK(hipMalloc(&h->lut, sizeof(lut)));
@@ -303,7 +331,22 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
         a.Cin = c.cin; a.Cout = c.cout; a.k = c.k; a.stride = c.s; a.pad = c.pad; a.act = c.act;
         if (a.Hout * (int)c.s != a.Hin || a.Wout * (int)c.s != a.Win) return fail(MI355_EFORMAT, "conv resolution mismatch in program");
         std::vector<ConvLaunch> cands;
-        KCHK(plan_conv_candidates(a, &cands));
+        if (h->fuse_up[i] >= 0) {
+            const FileOp& u = h->ops[h->fuse_up[i]];
+            ConvArgs f = a;
+            f.src2 = h->view(u.src_buf, u.src_choff); f.src2_cs = h->dbuf_cs[u.src_buf]; f.up_c = u.src_c;
+            const bool same_prec = h->dbuf_es[u.src_buf] == h->dbuf_es[o.src_buf];
+            const bool shape_ok = h->bufs[u.src_buf].stride_div == 2 * sd_in && (a.Hin % 2) == 0 && (a.Win % 2) == 0 &&
+                                  (u.src_c % (16 / h->dbuf_es[o.src_buf])) == 0;
+            if (same_prec && shape_ok && plan_conv_candidates(f, &cands) == nullptr && !cands.empty()) {
+                a = f;
+                h->fused_away[h->fuse_up[i]] = 1;
+            } else {                                    // no v4 plan for this shape: run the upsample kernel after all
+                cands.clear();
+                h->fused_away[h->fuse_up[i]] = 0;
+            }
+        }
+        if (cands.empty()) KCHK(plan_conv_candidates(a, &cands));
         h->plans[i] = cands[0];
         if (cached && (size_t)(*cached)[i] < cands.size()) {
             h->plans[i] = cands[(*cached)[i]];
@@ -448,6 +491,7 @@ static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, c
             KCHK(run_conv(l, h->stream));
             pf.end();
         } else if (o.type == OP_UPSAMPLE) {
+            if (h->fused_away[i]) continue;             // read by its only consumer straight from the half-size map
             const int sd_in = h->bufs[o.src_buf].stride_div;
             if (pf.begin(K_UPSAMPLE)) return fail(MI355_EHIP, "event");
             if (h->dbuf_es[o.src_buf] != h->dbuf_es[o.dst_buf]) return fail(MI355_EFORMAT, "upsample between buffers of different precision");
