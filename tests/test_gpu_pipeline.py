@@ -1,0 +1,87 @@
+"""BASELINE config 0 and the dataset sweep with the REAL engine: clips -> detection -> tracker -> the reference's CSV files."""
+import csv
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dataset(root, n_frames=6):
+    from tools import synth
+    lines = ["Abuse/Abuse001_x264.mp4"]
+    for k, label in enumerate(("Shoplifting", "Shopping")):
+        os.makedirs(os.path.join(root, label), exist_ok=True)
+        name = f"{label}00{k + 1}_x264"
+        np.save(os.path.join(root, label, name + ".npy"), synth.synthetic_frames(n_frames, 240, 320, seed=60 + k))
+        lines.append(f"{label}/{name}.mp4")
+    lst = os.path.join(root, "list.txt")
+    with open(lst, "w") as f:
+        f.write("\n".join(lines))
+    return lst
+
+
+def _read(path, missing_ok=False):
+    if missing_ok and not os.path.exists(path):
+        return []
+    with open(path, "rb") as f:
+        raw = f.read()
+    assert raw.endswith(b"\r\n") and b"\n" not in raw.replace(b"\r\n", b"")           # csv.writer's excel dialect
+    return list(csv.reader(raw.decode().splitlines()))
+
+
+def test_preprocess_loop_writes_the_reference_csv(v8n, tmp_path):
+    """preprocess.py:15-53 + model.py:36-81 with the engine in place of Ultralytics: one Shoplifting and one Shopping clip"""
+    from cvsd_amd import YOLO
+    from cvsd_amd import preprocess_driver as P
+    from cvsd_amd.tracker_csv import Tracker
+    root = str(tmp_path / "data")
+    os.makedirs(root)
+    lst = _dataset(root)
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    t = Tracker(model=YOLO.from_state_dict("yolov8n", v8n[1]), out_dir=out)
+    n = P.run(t, lst, root + "/", capture=P.NpyCapture, log=lambda *_: None)
+    assert n == 12
+    rows = _read(os.path.join(out, "ucf-crime_dataset.csv"))
+    assert rows, "the synthetic detector tracks something on these frames"
+    for r in rows:
+        clip, name, frame, person, left, top, width, height, is_anomaly, anomaly = r
+        assert clip == "2" and name == "Shoplifting001_x264.mp4" and 1 <= int(frame) <= 6      # list line 2, 1-based frames
+        assert float(person) >= 1 and is_anomaly == "True" and anomaly == "Shoplifting"
+        assert all(0.0 <= float(v) <= 1.0 for v in (left, top, width, height))                 # xywhn
+    normal = _read(os.path.join(out, "ucf-crime_dataset-normal.csv"))
+    assert normal and all(r[0] == "3" and r[8] == "False" and r[9] == "Shopping" for r in normal)
+
+
+def test_sweep_with_the_engine_matches_the_sequential_loop(v8n, tmp_path):
+    """cvsd_amd.sweep (batched detection, per-clip tracker) against the frame-by-frame loop: same detections per frame,
+    hence the same rows (ids are per clip in both when the loop's tracker is reset per clip)"""
+    from cvsd_amd import YOLO
+    from cvsd_amd import preprocess_driver as P
+    from cvsd_amd.sweep import sweep
+    root = str(tmp_path / "data")
+    os.makedirs(root)
+    lst = _dataset(root, n_frames=6)
+    m = YOLO.from_state_dict("yolov8n", v8n[1])
+    out = str(tmp_path / "sweep")
+    os.makedirs(out)
+    written = sweep(m, lst, root + "/", out_dir=out, batch=4, capture=P.NpyCapture, log=lambda *_: None)
+    rows = _read(os.path.join(out, "ucf-crime_dataset.csv"), True) + _read(os.path.join(out, "ucf-crime_dataset-normal.csv"), True)
+    assert written == len(rows) > 0
+    # reference-style loop, tracker reset at each clip
+    want = []
+    for i, label, name, rel in [(2, "Shoplifting", "Shoplifting001_x264.mp4", "Shoplifting/Shoplifting001_x264"),
+                                (3, "Shopping", "Shopping002_x264.mp4", "Shopping/Shopping002_x264")]:
+        m._tracker = None
+        clip = np.load(os.path.join(root, rel + ".npy"))
+        for k, frame in enumerate(clip, start=1):
+            b = m.track(frame, persist=True, show=False, classes=[0], verbose=False)[0].boxes
+            if b.is_track:
+                for box in b:
+                    want.append((str(i), name, str(k), float(box.id), [float(v) for v in box.xywhn[0]]))
+    assert len(want) == len(rows)
+    for r, w in zip(rows, want):
+        assert (r[0], r[1], r[2]) == w[:3]
+        np.testing.assert_allclose([float(v) for v in r[4:8]], w[4], rtol=0, atol=1e-6)
