@@ -595,10 +595,9 @@ static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, c
         }
         return MI355_OK;
     };
-    // several streams along the dependency DAG for small chunks (capture / profiling keep the single in-order stream)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(h->stream, &cap);
-    const bool multi = h->n_streams > 1 && !h->profiling && nb <= h->streams_max_batch && cap == hipStreamCaptureStatusNone;
+    // several streams along the dependency DAG (profiling keeps the single in-order stream; under hipGraph capture the
+    // event waits fork the aux streams into the capture and the decode join brings them back)
+    const bool multi = h->n_streams > 1 && !h->profiling && nb <= h->streams_max_batch;
     if (!multi) {
         for (size_t i = 0; i < h->ops.size(); ++i) { const int rc = launch_op(i, h->stream); if (rc) return rc; }
     } else {
