@@ -465,6 +465,12 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
     HIPCHK(hipMalloc(&h->keys, (size_t)nb * h->Apow2 * 8));
     HIPCHK(hipMalloc(&h->lbox, (size_t)nb * Hl * Wl * 3));
     h->cur_nb = nb; h->cur_H = Hl; h->cur_W = Wl;
+    if (getenv("MI355_SCHED_LOG")) {      // launch order of a pass for tools/layer_report.py: position, op index, stream, launched
+        for (size_t pos = 0; pos < h->sched_order.size(); ++pos) {
+            const int idx = h->sched_order[pos];
+            fprintf(stderr, "[sched] %zu %d %d %d\n", pos, idx, h->op_stream[idx], !(h->ops[idx].type == OP_UPSAMPLE && h->fused_away[idx]));
+        }
+    }
     return MI355_OK;
 }
 

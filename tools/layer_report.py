@@ -14,19 +14,42 @@ chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 size = int(sys.argv[4]) if len(sys.argv) > 4 else 640
 es = float(sys.argv[5]) if len(sys.argv) > 5 else 4.0      # activation element size: 4 = fp32, 2 = the half=True engine
 prog = build_program(*parse_model_name(model))
+sched_log = sys.argv[6] if len(sys.argv) > 6 else None      # bench log with the engine's "[sched] pos op stream launched" lines
 rows = [r for r in csv.DictReader(open(path)) if "mi355" in r["Kernel_Name"]]
-rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-seq = []
-for op in prog.ops:
-    seq.append({OP_STEM: "stem_", OP_CONV: "conv", OP_UPSAMPLE: "upsample2x", OP_SPPF_POOL: "sppf_pools"}[op.type])
-seq += ["decode_kernel", "nms_sort_kernel", "nms_greedy_kernel"]
-# split the trace into passes
+rows.sort(key=lambda r: int(r["Dispatch_Id"]))              # host enqueue order (kernels of different streams overlap in time)
+kind = {OP_STEM: "stem_", OP_CONV: "conv", OP_UPSAMPLE: "upsample2x", OP_SPPF_POOL: "sppf_pools"}
+tail = ["decode_kernel", "nms_sort_kernel", "nms_greedy_kernel"]
+orders = [list(range(len(prog.ops)))]                       # program order (profiling passes) ...
+launched = {i: True for i in range(len(prog.ops))}
+if sched_log and os.path.exists(sched_log):
+    sched = []
+    for l in open(sched_log):
+        if l.startswith("[sched] "):
+            _, pos, op, stream, on = l.split()
+            if int(pos) == 0: sched = []
+            sched.append(int(op)); launched[int(op)] = on == "1"
+    if sched: orders.append(sched)                          # ... and the multi-stream schedule (timed passes)
+# split the trace into passes: a pass is the kernel sequence of one of the orders (ops that are fused away are not launched)
+cands = []
+for o in orders:
+    ops_l = [i for i in o if launched[i]]
+    cands.append((ops_l, [kind[prog.ops[i].type] for i in ops_l] + tail))
 passes, i = [], 0
-while i + len(seq) <= len(rows):
-    if all(seq[j] in rows[i + j]["Kernel_Name"] for j in range(len(seq))):
-        passes.append(rows[i:i + len(seq)]); i += len(seq)
+while i < len(rows):
+    hit = None
+    for ops_l, names in cands:
+        if i + len(names) <= len(rows) and all(names[j] in rows[i + j]["Kernel_Name"] for j in range(len(names))):
+            hit = (ops_l, names); break
+    if hit:
+        # store the pass re-ordered into program order of the launched ops, so that column j means the same op in every pass
+        ops_l, names = hit
+        by_op = {op: rows[i + j] for j, op in enumerate(ops_l)}
+        prog_l = [k for k in range(len(prog.ops)) if launched[k]]
+        passes.append([by_op[k] for k in prog_l] + rows[i + len(ops_l):i + len(names)]); i += len(names)
     else:
         i += 1
+prog_l = [k for k in range(len(prog.ops)) if launched[k]]
+seq = [kind[prog.ops[k].type] for k in prog_l] + tail
 print(f"{len(passes)} passes of {len(seq)} launches matched ({model}, chunk {chunk})")
 tot = 0.0
 print(f"{'op':26s} {'kernel<KS,S,PT,CT,WP>':24s} {'shape':30s} {'grid':>12s} {'lds':>6s} {'vgpr':>5s} {'us':>8s} {'TFLOP/s':>8s} {'GB/s':>7s}")
@@ -36,8 +59,8 @@ for j, name in enumerate(seq):
     r = passes[0][j]
     kn = r["Kernel_Name"]
     tmpl = kn[kn.find("<"):kn.find(">") + 1] if "<" in kn else ""
-    if j < len(prog.ops) and prog.ops[j].type in (OP_CONV, OP_STEM):
-        op = prog.ops[j]; c = prog.convs[op.conv]
+    if j < len(prog_l) and prog.ops[prog_l[j]].type in (OP_CONV, OP_STEM):
+        op = prog.ops[prog_l[j]]; c = prog.convs[op.conv]
         hw = (size // c.stride_div) ** 2
         fl = 2.0 * c.cout * c.cin * c.k * c.k * hw * chunk
         by = es * chunk * (c.cin * hw * c.s * c.s + c.cout * hw)

@@ -14,7 +14,7 @@ shutil.copy(g(f"{tag}_trace/*/*kernel_stats.csv"), os.path.join(ROOT, "profiles"
 with open(os.path.join(ROOT, "profiles", f"{tag}_bench_under_rocprof.json"), "w") as f:
     f.write([l for l in open(os.path.join(ROOT, "gpurun_out", f"{tag}_trace.log")) if l.startswith('{"metric')][-1])
 rep = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "layer_report.py"), g(f"{tag}_trace/*/*kernel_trace.csv"), model, str(batch),
-                      str(size), str(es)], capture_output=True, text=True)
+                      str(size), str(es), os.path.join(ROOT, "gpurun_out", f"{tag}_trace.log")], capture_output=True, text=True)
 open(os.path.join(ROOT, "profiles", f"{tag}_layer_report.txt"), "w").write(rep.stdout)
 print(rep.stdout[-600:], rep.stderr[-2000:])
 
@@ -48,7 +48,7 @@ try:
     busy = conv_sum(pat, "SQ_VALU_MFMA_BUSY_CYCLES"); sq = conv_sum(pat, "SQ_BUSY_CYCLES"); gui = conv_sum(pat, "GRBM_GUI_ACTIVE")
     out["mfma_counters_per_step"] = {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_BUSY_CYCLES": sq, "GRBM_GUI_ACTIVE": gui,
                                      "note": "sums over the conv dispatches of one step; GRBM_GUI_ACTIVE is the sum over the 8 XCDs"}
-except (IndexError, FileNotFoundError):
+except (IndexError, FileNotFoundError, ValueError):
     pass
 name = "r01_conv_traffic.json" if tag == "r01_v3" else f"{tag}_conv_traffic.json"
 json.dump(out, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
