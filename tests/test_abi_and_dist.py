@@ -96,3 +96,28 @@ def test_shard_range_covers_everything():
         for world in (1, 2, 4, 8):
             r = [shard_range(total, k, world) for k in range(world)]
             assert r[0][0] == 0 and r[-1][1] == total and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """include/mi355_yolo.h must be consumable from C (the drop-in boundary is a C ABI, not a C++ one): a C99 client that
+    references every entry point compiles with gcc and links against libmi355yolo.so."""
+    import re
+    import shutil
+    import subprocess
+    from cvsd_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(ROOT, "include", "mi355_yolo.h")
+    names = sorted(set(re.findall(r"\b(mi355_[a-z0-9_]+)\s*\(", open(hdr).read())))
+    assert "mi355_yolo_infer" in names and "mi355_yolo_create" in names
+    src = tmp_path / "client.c"
+    body = "\n".join(f"    p[{i}] = (void*)&{n};" for i, n in enumerate(names))
+    src.write_text('#include "mi355_yolo.h"\n#include <stdio.h>\nint main(void) {\n    mi355_opts o = {0}; mi355_det d; void* p[%d];\n'
+                   '    o.struct_size = (int)sizeof o; (void)d;\n%s\n    printf("%%d %%d\\n", (int)sizeof(mi355_det), o.struct_size);\n    return p[0] == 0;\n}\n'
+                   % (len(names), body))
+    so = _lib.LIB_PATH
+    exe = tmp_path / "client"
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), so,
+                        "-Wl,-rpath," + os.path.dirname(so)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
