@@ -112,6 +112,10 @@ const char* launch_decode(const DecodeArgs& a, bool full, hipStream_t st);
 const char* launch_best_from_pred(const float* pred_anchor_major, int B, int A, int no, int nc, float2* best,
                                   hipStream_t st);
 const char* launch_transpose_pred(const float* in, float* out, int B, int rows, int cols, hipStream_t st);
+// rows [n][max_det] (first counts[i] valid) -> packed [sum counts] in frame order; offsets[n + 1] = exclusive scan of counts.
+// The host then copies sum(counts) rows instead of n * max_det (35 MB -> ~3 MB per 512-frame step).
+const char* launch_compact_rows(const void* rows, const int* counts, int n, int max_det, int row_words, int* offsets, void* packed,
+                                hipStream_t st);
 
 struct NmsArgs {
     const float* pred; const float2* best;     // as written by decode

@@ -157,6 +157,7 @@ struct mi355_yolo {
     uint8_t* d_in = nullptr; size_t d_in_bytes = 0;
     mi355_det* d_rows = nullptr; int* d_counts = nullptr; size_t rows_cap = 0; int counts_cap = 0;
     mi355_det* h_rows = nullptr; int* h_counts = nullptr; size_t h_rows_cap = 0; int h_counts_cap = 0;
+    mi355_det* d_packed = nullptr; int* d_offsets = nullptr; size_t packed_cap = 0; int offsets_cap = 0;   // rows compacted on the GPU before the D2H copy
     unsigned* d_cmask = nullptr; unsigned* h_cmask = nullptr; int cmask_words = 0;
     int* d_xtab = nullptr; int* d_ytab = nullptr; int tab_h0 = -1, tab_w0 = -1, tab_imgsz = -1;
     float* d_rawhead = nullptr; size_t rawhead_floats = 0;
@@ -190,6 +191,7 @@ mi355_yolo::~mi355_yolo() {
     if (zeros) (void)hipFree(zeros);
     if (d_in) (void)hipFree(d_in);
     if (d_rows) (void)hipFree(d_rows); if (d_counts) (void)hipFree(d_counts);
+    if (d_packed) (void)hipFree(d_packed); if (d_offsets) (void)hipFree(d_offsets);
     if (h_rows) (void)hipHostFree(h_rows); if (h_counts) (void)hipHostFree(h_counts);
     if (d_cmask) (void)hipFree(d_cmask); if (h_cmask) (void)hipHostFree(h_cmask);
     if (d_xtab) (void)hipFree(d_xtab); if (d_ytab) (void)hipFree(d_ytab);
@@ -717,6 +719,14 @@ static int infer_impl(mi355_yolo* h, const uint8_t* src, bool src_on_device, int
         if (h->d_counts) (void)hipFree(h->d_counts); h->d_counts = nullptr; h->counts_cap = 0;
         HIPCHK(hipMalloc(&h->d_counts, (size_t)2 * n * sizeof(int) + 2 * h->chunk * sizeof(int))); h->counts_cap = 2 * n;
     }
+    if (h->packed_cap < (size_t)n * max_det) {
+        if (h->d_packed) (void)hipFree(h->d_packed); h->d_packed = nullptr; h->packed_cap = 0;
+        HIPCHK(hipMalloc(&h->d_packed, (size_t)n * max_det * sizeof(mi355_det))); h->packed_cap = (size_t)n * max_det;
+    }
+    if (h->offsets_cap < n + 1) {
+        if (h->d_offsets) (void)hipFree(h->d_offsets); h->d_offsets = nullptr; h->offsets_cap = 0;
+        HIPCHK(hipMalloc(&h->d_offsets, (size_t)(n + 1) * sizeof(int))); h->offsets_cap = n + 1;
+    }
     if (h->h_rows_cap < (size_t)n * max_det) {
         if (h->h_rows) (void)hipHostFree(h->h_rows); h->h_rows = nullptr; h->h_rows_cap = 0;
         HIPCHK(hipHostMalloc(&h->h_rows, (size_t)n * max_det * sizeof(mi355_det))); h->h_rows_cap = (size_t)n * max_det;
@@ -779,13 +789,23 @@ static int infer_impl(mi355_yolo* h, const uint8_t* src, bool src_on_device, int
         pf.end();
     }
     HIPCHK(hipEventRecord(h->ev1, h->stream));
+    // rows -> host: compact on the GPU first (a frame keeps counts[i] of its max_det slots; copying the slots would be 35 MB
+    // per 512 frames), then two small copies: the counts, and sum(counts) rows
+    KCHK(launch_compact_rows(h->d_rows, h->d_counts, n, max_det, (int)(sizeof(mi355_det) / 4), h->d_offsets, h->d_packed, h->stream));
     HIPCHK(hipMemcpyAsync(h->h_counts, h->d_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(h->h_rows, h->d_rows, (size_t)n * max_det * sizeof(mi355_det), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += (size_t)h->h_counts[i];
+    if (total) {
+        HIPCHK(hipMemcpyAsync(h->h_rows, h->d_packed, total * sizeof(mi355_det), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    size_t at = 0;
     for (int i = 0; i < n; ++i) {
         const int c = std::min(h->h_counts[i], cap);
         out_counts[i] = c;
-        std::memcpy(out_rows + (size_t)i * cap, h->h_rows + (size_t)i * max_det, (size_t)c * sizeof(mi355_det));
+        std::memcpy(out_rows + (size_t)i * cap, h->h_rows + at, (size_t)c * sizeof(mi355_det));
+        at += (size_t)h->h_counts[i];
     }
     return collect_timing(h, pf, n);
 }

@@ -688,4 +688,42 @@ const char* launch_nms(const NmsArgs& a, hipStream_t st) {
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
 
+// ---------------------------------------------------------------------------------------------- row compaction
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const int* counts, int n, int* offsets) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    int sum = 0;
+    for (int i = tid * per; i < n && i < (tid + 1) * per; ++i) sum += counts[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {              // Hillis-Steele inclusive scan of the 1024 partial sums
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = tid ? part[tid - 1] : 0;
+    for (int i = tid * per; i < n && i < (tid + 1) * per; ++i) { offsets[i] = run; run += counts[i]; }
+    if (tid == 1023) offsets[n] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void compact_rows_kernel(const unsigned* rows, const int* counts, const int* offsets, int max_det,
+                                                           int row_words, unsigned* packed) {
+    const int i = blockIdx.x;
+    const int words = counts[i] * row_words;
+    const unsigned* src = rows + (size_t)i * max_det * row_words;
+    unsigned* dst = packed + (size_t)offsets[i] * row_words;
+    for (int w = threadIdx.x; w < words; w += 256) dst[w] = src[w];
+}
+
+const char* launch_compact_rows(const void* rows, const int* counts, int n, int max_det, int row_words, int* offsets, void* packed,
+                                hipStream_t st) {
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, st, counts, n, offsets);
+    hipLaunchKernelGGL(compact_rows_kernel, dim3(n), dim3(256), 0, st, (const unsigned*)rows, counts, offsets, max_det, row_words,
+                       (unsigned*)packed);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
 }  // namespace mi355

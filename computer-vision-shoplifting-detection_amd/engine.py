@@ -145,7 +145,7 @@ class YOLO:
         hnd = self._handle(half)
         self._last_handle = hnd
         n, h, w = int(batch.shape[0]), int(batch.shape[1]), int(batch.shape[2])
-        rows = np.zeros((n, max_det, _lib.DET_WORDS), dtype=np.float32)
+        rows = np.empty((n, max_det, _lib.DET_WORDS), dtype=np.float32)    # only rows[i, :counts[i]] are written / meaningful
         counts = np.zeros(n, dtype=np.int32)
         cls_arr = None
         ncls = 0
