@@ -17,7 +17,7 @@
  *   stem      acc = +0; for kh: for kw: for byte channel (B, G, R): acc = fmaf(lut[byte], w[co][2-ch][kh][kw], acc)
  *             with lut[i] = (float)i / 255.0f; y = silu(acc + bias).
  *   exp       det_expf below (Cody-Waite reduction + degree-5 polynomial, fmaf only, no libm);
- *             silu(v) = v / (1 + det_expf(-v)); sigmoid(v) = 1 / (1 + det_expf(-v)).
+ *             silu(v) = v / (1 + det_expf_silu(-v)) (range-restricted exp, same bits on [-87.25, 88]); sigmoid(v) = 1 / (1 + det_expf(-v)).
  *   decode    as ultralytics head.py / tal.py, evaluated left to right without contraction (see det_decode).
  * Compile with -ffp-contract=off -mfma: every fused operation is an explicit fmaf().
  */
@@ -49,7 +49,27 @@ float det_expf(float x) {
     return (e * s1) * s2;
 }
 
-static inline float det_silu(float v) { return v / (1.0f + det_expf(-v)); }
+/* exp for SiLU only (csrc/detmath.h:det_expf_silu): argument clamped to [-87.25, 88] where 2^n is a normal float, one exact
+ * scaling; identical bits to det_expf inside that range. */
+static inline float det_expf_silu(float x) {
+    x = fminf(fmaxf(x, -87.25f), 88.0f);
+    const float t = fmaf(x, 1.44269504088896341f, 12582912.0f);
+    const float n = t - 12582912.0f;
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.428606765330187045e-06f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    float e = fmaf(p, r2, r);
+    e = e + 1.0f;
+    return e * int_as_float(((int32_t)n + 127) << 23);
+}
+
+static inline float det_silu(float v) { return v / (1.0f + det_expf_silu(-v)); }
 static inline float det_sigmoid(float v) { return 1.0f / (1.0f + det_expf(-v)); }
 
 void det_expf_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = det_expf(x[i]); }
