@@ -85,3 +85,27 @@ def test_sweep_with_the_engine_matches_the_sequential_loop(v8n, tmp_path):
     for r, w in zip(rows, want):
         assert (r[0], r[1], r[2]) == w[:3]
         np.testing.assert_allclose([float(v) for v in r[4:8]], w[4], rtol=0, atol=1e-6)
+
+
+def test_pose_clip_to_poselift_pickle(v8n_pose, tmp_path):
+    """config 2's consumer format: frames -> YOLOv8n-pose engine (batched) -> host tracker -> the per-video pickle
+    {frame: {person: [bbox, keypoints(17,3)]}} that shopformer/data/poselift_dataset.py:256-295 reads"""
+    import pickle
+    from cvsd_amd import YOLO
+    from cvsd_amd.poselift_bridge import video_to_poselift
+    from tools import synth
+    m = YOLO.from_state_dict("yolov8n-pose", v8n_pose[1])
+    frames = synth.synthetic_frames(10, 240, 320, seed=77)
+    out = str(tmp_path / "Shoplifting001.pkl")
+    data = video_to_poselift(m, list(frames), out_path=out, conf=0.25, batch=4)
+    with open(out, "rb") as f:
+        assert pickle.load(f).keys() == data.keys()
+    assert sorted(data) == list(range(10))                                  # one entry per frame, 0-based like PoseLift
+    persons = [p for fr in data.values() for p in fr.items()]
+    assert persons, "the synthetic pose model tracks somebody on these frames"
+    for pid, (bbox, kp) in persons:
+        assert isinstance(pid, int) and pid >= 1
+        assert bbox.shape == (4,) and bbox[2] > 0 and bbox[3] > 0           # x, y, w, h in pixels of the 320x240 frame
+        assert kp.shape == (17, 3) and np.isfinite(kp).all() and (kp[:, 2] >= 0).all() and (kp[:, 2] <= 1).all()
+    # ids persist: some person is present in at least two consecutive frames
+    assert any(set(data[k]) & set(data[k + 1]) for k in range(9))
