@@ -218,13 +218,14 @@ class YOLO:
             res = self.predict(batch[i:i + 1], conf=conf, **kwargs)[0]
             if originals is not None:
                 res.orig_img = originals[i]
-            det = res.boxes.data.numpy()
-            if len(det):
-                tracks = self._tracker.update(det)
-                if len(tracks):
-                    idx = tracks[:, -1].astype(int)
-                    res = res[idx]
-                    res.update(boxes=torch.as_tensor(tracks[:, :-1], dtype=torch.float32))
+            # trackers/track.py:on_predict_postprocess_end: the tracker steps on EVERY frame (an empty frame still advances
+            # frame_id, ages lost tracks against track_buffer and runs the Kalman predict); only the rewrite of the
+            # result is skipped when no track comes back
+            tracks = self._tracker.update(res.boxes.data.numpy())
+            if len(tracks):
+                idx = tracks[:, -1].astype(int)
+                res = res[idx]
+                res.update(boxes=torch.as_tensor(tracks[:, :-1], dtype=torch.float32))
             results.append(res)
         return results
 

@@ -42,6 +42,7 @@ def video_to_poselift(model, frames: Iterable[np.ndarray], out_path: Optional[st
                       batch: int = 64, first_frame: int = 0, **predict_kw) -> Dict[int, Dict[int, list]]:
     """Run a pose model over the frames of ONE video and build its PoseLift dict (optionally pickled to ``out_path``).
     Detection runs in batches on the GPU; tracking is sequential on the host, in frame order."""
+    from .results import clip_boxes
     from .tracker import BYTETracker
     if getattr(model, "task", "pose") != "pose":
         raise ValueError("video_to_poselift needs a pose model (e.g. yolov8n-pose)")
@@ -54,9 +55,9 @@ def video_to_poselift(model, frames: Iterable[np.ndarray], out_path: Optional[st
         if not buf:
             return
         for res in model.predict(np.stack(buf), conf=min(conf, 0.1), **predict_kw):
-            det = res.boxes.data.numpy()
-            rows = tracker.update(det) if len(det) else np.zeros((0, 8), np.float32)
+            rows = tracker.update(res.boxes.data.numpy())      # every frame, empty ones too (frame_id / lost-track ageing)
             if len(rows):
+                rows = clip_boxes(rows.copy(), res.orig_shape)  # Results.update clips the track boxes to the frame
                 idx = rows[:, -1].astype(int)
                 keep = rows[:, 5] >= conf                              # tracker sees conf >= 0.1, the file keeps conf >= conf
                 raw = res.keypoints_raw if hasattr(res, "keypoints_raw") else res.keypoints.data.numpy()

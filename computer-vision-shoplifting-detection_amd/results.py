@@ -59,6 +59,20 @@ def xyxy2xywh(x):
     return y
 
 
+def clip_boxes(boxes, shape):
+    """utils/ops.py:clip_boxes -- x1,x2 to [0, w], y1,y2 to [0, h] on the first four columns, in place; shape = (h, w)."""
+    h, w = shape[:2]
+    if isinstance(boxes, np.ndarray):
+        boxes[..., [0, 2]] = boxes[..., [0, 2]].clip(0, w)
+        boxes[..., [1, 3]] = boxes[..., [1, 3]].clip(0, h)
+    else:
+        boxes[..., 0].clamp_(0, w)
+        boxes[..., 1].clamp_(0, h)
+        boxes[..., 2].clamp_(0, w)
+        boxes[..., 3].clamp_(0, h)
+    return boxes
+
+
 class Boxes(_BaseTensor):
     """data: [N, 6] = x1,y1,x2,y2,conf,cls   or   [N, 7] = x1,y1,x2,y2,track_id,conf,cls (tracking)."""
 
@@ -160,9 +174,11 @@ class Results:
         return r
 
     def update(self, boxes=None):
-        """engine/results.py:Results.update -- the tracker callback replaces the box tensor with track rows."""
+        """engine/results.py:Results.update -- the tracker callback replaces the box tensor with track rows, clipped to
+        the image like ``Boxes(ops.clip_boxes(boxes, self.orig_shape), self.orig_shape)`` (the rows are Kalman-state boxes
+        and may overhang the frame; the reference's CSV reads ``xywhn`` of the clipped ones)."""
         if boxes is not None:
-            self.boxes = Boxes(boxes, self.orig_shape)
+            self.boxes = Boxes(clip_boxes(boxes, self.orig_shape), self.orig_shape)
 
     def cpu(self):
         return self

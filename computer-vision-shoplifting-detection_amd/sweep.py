@@ -42,7 +42,7 @@ def list_clips(list_path: str, videos_to_process: Optional[List[str]] = None) ->
 def process_clip(model, cap, batch: int = 64, conf: float = 0.1, classes=(0,), **predict_kw) -> np.ndarray:
     """All tracked boxes of one clip: array [rows, 6] = frame number (1-based), local track id, xywhn (centre x, centre y,
     w, h).  Detection is batched; the tracker sees the frames one by one, in order (model.py:38 semantics)."""
-    from .results import Boxes
+    from .results import Boxes, clip_boxes
     from .tracker import BYTETracker
     import torch
     tracker = BYTETracker()
@@ -53,10 +53,9 @@ def process_clip(model, cap, batch: int = 64, conf: float = 0.1, classes=(0,), *
         if not buf:
             return
         for n, res in zip(nums, model.predict(np.stack(buf), conf=conf, classes=list(classes), **predict_kw)):
-            det = res.boxes.data.numpy()
-            tracks = tracker.update(det) if len(det) else np.zeros((0, 8), np.float32)
+            tracks = tracker.update(res.boxes.data.numpy())    # every frame, empty ones too (frame_id / lost-track ageing)
             if len(tracks):                                    # `if not boxes.is_track: return` otherwise (model.py:45)
-                b = Boxes(torch.as_tensor(tracks[:, :-1], dtype=torch.float32), res.orig_shape)
+                b = Boxes(clip_boxes(torch.as_tensor(tracks[:, :-1], dtype=torch.float32), res.orig_shape), res.orig_shape)
                 for box in b:
                     x = box.xywhn[0]
                     rows.append([float(int(n)), float(box.id), float(x[0]), float(x[1]), float(x[2]), float(x[3])])

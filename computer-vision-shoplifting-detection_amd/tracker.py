@@ -80,8 +80,6 @@ class KalmanFilterXYWH:
 
 
 class STrack:
-    _count = 0
-
     def __init__(self, xywh_idx, score, cls):
         self._xywh = np.asarray(xywh_idx[:4], dtype=np.float32)       # centre x, y, w, h
         self.idx = xywh_idx[-1]
@@ -94,15 +92,6 @@ class STrack:
         self.tracklet_len = 0
         self.frame_id = self.start_frame = 0
 
-    @staticmethod
-    def next_id():
-        STrack._count += 1
-        return STrack._count
-
-    @staticmethod
-    def reset_id():
-        STrack._count = 0
-
     @property
     def end_frame(self):
         return self.frame_id
@@ -114,9 +103,9 @@ class STrack:
             mean[7] = 0
         self.mean, self.covariance = self.kalman_filter.predict(mean, self.covariance)
 
-    def activate(self, kalman_filter, frame_id):
+    def activate(self, kalman_filter, frame_id, track_id):
         self.kalman_filter = kalman_filter
-        self.track_id = self.next_id()
+        self.track_id = track_id
         self.mean, self.covariance = kalman_filter.initiate(self._xywh.astype(np.float64))
         self.tracklet_len = 0
         self.state = TRACKED
@@ -124,14 +113,12 @@ class STrack:
             self.is_activated = True
         self.frame_id = self.start_frame = frame_id
 
-    def re_activate(self, new_track, frame_id, new_id=False):
+    def re_activate(self, new_track, frame_id):
         self.mean, self.covariance = self.kalman_filter.update(self.mean, self.covariance, new_track._xywh.astype(np.float64))
         self.tracklet_len = 0
         self.state = TRACKED
         self.is_activated = True
         self.frame_id = frame_id
-        if new_id:
-            self.track_id = self.next_id()
         self.score, self.cls, self.idx = new_track.score, new_track.cls, new_track.idx
 
     def update(self, new_track, frame_id):
@@ -238,7 +225,14 @@ class BYTETracker:
         self.frame_id = 0
         self.max_time_lost = int(frame_rate / 30.0 * TRACK_BUFFER)
         self.kalman_filter = KalmanFilterXYWH()
-        STrack.reset_id()
+        # ids are owned by the tracker instance (1, 2, ... in activation order): a second tracker created while this one is
+        # alive (sweep / poselift bridge next to model.track(persist=True)) cannot disturb them.  For one tracker per process
+        # this is what Ultralytics' class-wide BaseTrack counter + reset_id() in __init__ produces.
+        self._ids_issued = 0
+
+    def _next_id(self) -> int:
+        self._ids_issued += 1
+        return self._ids_issued
 
     @staticmethod
     def _init_track(dets, scores, cls):
@@ -269,7 +263,7 @@ class BYTETracker:
                 t.update(d, self.frame_id)
                 activated.append(t)
             else:
-                t.re_activate(d, self.frame_id, new_id=False)
+                t.re_activate(d, self.frame_id)
                 refind.append(t)
         det2 = self._init_track(xywh[second], scores[second], cls[second])
         r_tracked = [pool[i] for i in u_track if pool[i].state == TRACKED]
@@ -280,7 +274,7 @@ class BYTETracker:
                 t.update(d, self.frame_id)
                 activated.append(t)
             else:
-                t.re_activate(d, self.frame_id, new_id=False)
+                t.re_activate(d, self.frame_id)
                 refind.append(t)
         for it in u_track2:
             t = r_tracked[it]
@@ -302,7 +296,7 @@ class BYTETracker:
             t = detections[inew]
             if t.score < NEW_TRACK_THRESH:
                 continue
-            t.activate(self.kalman_filter, self.frame_id)
+            t.activate(self.kalman_filter, self.frame_id, self._next_id())
             activated.append(t)
         for t in self.lost_stracks:
             if self.frame_id - t.end_frame > self.max_time_lost:
