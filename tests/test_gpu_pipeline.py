@@ -109,3 +109,31 @@ def test_pose_clip_to_poselift_pickle(v8n_pose, tmp_path):
         assert kp.shape == (17, 3) and np.isfinite(kp).all() and (kp[:, 2] >= 0).all() and (kp[:, 2] <= 1).all()
     # ids persist: some person is present in at least two consecutive frames
     assert any(set(data[k]) & set(data[k + 1]) for k in range(9))
+
+
+def test_engine_to_poselift_reproduces_the_reference_loader_fixture(v8n_pose):
+    """SURVEY 8(f) rank 1, pinned by the reference itself: tests/golden/poselift_fixture.npz holds the bridge dict of a
+    20-frame synthetic clip (canonical-oracle detections) and what /root/reference/shopformer/data/poselift_dataset.py:
+    PoseLiftDataset made of its pickle tree (generated in the build container, tests/golden/make_poselift_fixture.py).
+    The real engine through the same bridge must give the same dict bit for bit, hence the same training windows."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from _poselift_windows import unflatten, windows
+    from cvsd_amd import YOLO
+    from cvsd_amd.poselift_bridge import video_to_poselift
+    from tools import synth
+    fix = np.load(os.path.join(os.path.dirname(__file__), "golden", "poselift_fixture.npz"))
+    n, h, w, seed, imgsz, batch, seq_len, stride = (int(v) for v in fix["meta"])
+    m = YOLO.from_state_dict("yolov8n-pose", v8n_pose[1])
+    data = video_to_poselift(m, list(synth.synthetic_clip(n, h, w, seed=seed)), conf=float(fix["conf"]), batch=batch, imgsz=imgsz)
+    want = unflatten(fix["frame_keys"], fix["row_frame"], fix["row_pid"], fix["row_bbox"], fix["row_kpts"])
+    assert list(data) == list(want)
+    for f in want:
+        assert list(data[f]) == list(want[f]), f"frame {f}: person ids differ"
+        for pid in want[f]:
+            np.testing.assert_array_equal(data[f][pid][0], want[f][pid][0])
+            np.testing.assert_array_equal(data[f][pid][1], want[f][pid][1])
+    for split, labels in (("train", None), ("test", fix["gt"])):
+        x, y = windows(data, seq_len=seq_len, stride=stride, include_confidence=True, frame_labels=labels)
+        np.testing.assert_array_equal(x, fix[f"{split}_xyc_x"])
+        np.testing.assert_array_equal(y, fix[f"{split}_xyc_y"])

@@ -122,3 +122,18 @@ def synthetic_frames(n: int, h: int = 640, w: int = 640, seed: int = 0) -> np.nd
         noise = rng.integers(-48, 49, size=(h, w, 3))
         frames[i] = np.clip(img + noise, 0, 255).astype(np.uint8)
     return frames
+
+
+def synthetic_clip(n: int, h: int, w: int, seed: int = 0) -> np.ndarray:
+    """A short 'video' [n,h,w,3]: ONE synthetic scene that drifts by one pixel every second frame (consecutive
+    detections overlap, so a tracker keeps its ids) plus a little per-frame sensor noise.  Used by the PoseLift fixture
+    (tests/golden/make_poselift_fixture.py) and the GPU test that must reproduce it."""
+    base = synthetic_frames(1, h + 16, w + 16, seed=seed)[0]
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        d = k // 2
+        f = base[d:d + h, d:d + w].astype(np.int16)
+        f += rng.integers(-2, 3, size=f.shape, dtype=np.int16)
+        out.append(np.clip(f, 0, 255).astype(np.uint8))
+    return np.stack(out)
