@@ -23,6 +23,47 @@ def test_det_expf_accuracy_and_golden():
     np.testing.assert_array_equal(det.expf(G["expf/x"]), G["expf/y"])
 
 
+def _ulp_err(got32: np.ndarray, exact64: np.ndarray) -> np.ndarray:
+    """|got - exact| in units of the fp32 ulp AT the exact value (subnormal range: the fixed 2^-149 spacing)"""
+    ulp = np.maximum(np.spacing(np.abs(exact64).astype(np.float32)).astype(np.float64), 2.0 ** -149)
+    return np.abs(got32.astype(np.float64) - exact64) / ulp
+
+
+def test_det_expf_within_2ulp_of_libm_over_the_whole_range():
+    """det_expf is shared by the GPU kernels and the C oracle, so a flaw in it would pass every bit-exact test.
+    Pin it against libm's exp (float64, then the distance is measured in fp32 ulps): every fp32 argument on a dense grid of
+    the normal-output range [-87.3, 88.7] plus 2M random ones -- <= 2 ulp (measured 1.4); the gradual-underflow range down to
+    -104 within 1 ulp of the subnormal spacing + the double rounding of the two-step scaling; exact saturation outside."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([np.linspace(-87.3, 88.7, 1_000_001), rng.uniform(-87.3, 88.7, 2_000_000),
+                        rng.normal(0, 4, 1_000_000).clip(-87.3, 88.7)]).astype(np.float32)
+    err = _ulp_err(det.expf(x), np.exp(x.astype(np.float64)))
+    assert err.max() <= 2.0, err.max()
+    assert np.quantile(err, 0.999) <= 1.0
+    xs = np.linspace(-104.0, -87.3, 400_001).astype(np.float32)           # subnormal results
+    assert _ulp_err(det.expf(xs), np.exp(xs.astype(np.float64))).max() <= 2.0
+    big = np.array([88.72, 89.0, 100.0, 1e30, np.inf], np.float32)
+    assert np.isinf(det.expf(big)[1:]).all() and np.isfinite(det.expf(big)[0])
+    small = np.array([-104.0, -150.0, -1e30, -np.inf], np.float32)
+    assert (det.expf(small)[1:] == 0).all()
+    # monotone non-decreasing on the grid (a polynomial/reduction seam would show as a dip)
+    g = det.expf(np.linspace(-20, 20, 2_000_001).astype(np.float32))
+    assert (np.diff(g.astype(np.float64)) >= 0).all()
+
+
+def test_det_silu_and_sigmoid_against_float64():
+    """silu(v) = v / (1 + exp(-v)), sigmoid(v) = 1 / (1 + exp(-v)) with the canonical exp and IEEE division: within 3 ulp of
+    the float64 value wherever the result is a normal float (exp <= 2 ulp, the add and the division half an ulp each)."""
+    rng = np.random.default_rng(1)
+    v = np.concatenate([np.linspace(-80, 80, 400_001), rng.normal(0, 3, 1_000_000)]).astype(np.float32)
+    y = np.empty_like(v)
+    det.lib().det_silu_array(np.ascontiguousarray(v).ctypes.data, y.ctypes.data, v.size)
+    v64 = v.astype(np.float64)
+    assert _ulp_err(y, v64 / (1.0 + np.exp(-v64))).max() <= 3.0
+    sg = (np.float32(1.0) / (np.float32(1.0) + det.expf(-v))).astype(np.float32)
+    assert _ulp_err(sg, 1.0 / (1.0 + np.exp(-v64))).max() <= 3.0
+
+
 @pytest.mark.parametrize("tag", ["conv3x3_s1_res", "conv3x3_s2", "conv1x1_51"])
 def test_conv_golden_and_vs_torch(tag):
     x, w, b = G[f"{tag}/x"], G[f"{tag}/w"], G[f"{tag}/b"]
