@@ -12,8 +12,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmi355yolo.so")
-SOURCES = ["conv_igemm.hip", "conv_igemm_f16.hip", "misc_kernels.hip", "post_kernels.hip", "engine.hip"]
-HEADERS = ["common.h", "detmath.h", os.path.join("..", "..", "include", "mi355_yolo.h")]
+SOURCES = ["conv_f32_k3s1.hip", "conv_f32_k3s2.hip", "conv_f32_k1.hip", "conv_f32_pipe.hip", "conv_igemm_f16.hip", "conv_plan.hip",
+           "misc_kernels.hip", "post_kernels.hip", "engine.hip"]
+HEADERS = ["common.h", "detmath.h", "conv_f32.h", "conv_f32_inst.h", os.path.join("..", "..", "include", "mi355_yolo.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-result"]
 
 
@@ -50,7 +51,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
         return r
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])

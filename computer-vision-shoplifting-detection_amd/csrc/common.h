@@ -19,7 +19,7 @@ struct ConvArgs {
     int B, Hin, Win, Hout, Wout;
     int Cin, Cout;
     int k, stride, pad, act;           // k in {1,3}; act: 0 none, 1 SiLU
-    const float* zeros;                // device pointer to >= 16 zero bytes, or nullptr (then only v1 plans are offered)
+    const float* zeros;                // device pointer to >= 16 zero bytes (required)
     // half=True path (conv_igemm_f16.hip): dtype 1 = src / res / wpk hold fp16 (pack_conv_weights_f16), strides count halfs;
     // dst holds fp16 too unless out_f32 (the head's final convs).  The pointers keep their float* type; only bytes matter.
     int dtype = 0, out_f32 = 0;
@@ -52,12 +52,11 @@ struct ConvKArgs {
     int TW, TH, tiles_x, tiles_y, TWin, npix_in;
     float inv_TW, inv_TWin;
     int pad, act;
-    const float* zeros;        // >= 16 bytes of zeros (source of out-of-image / beyond-Cin slots of the v2 LDS-DMA loader)
+    const float* zeros;        // >= 16 bytes of zeros: what out-of-image / beyond-Cin slots read (loads stay unconditional)
     int out_f32;               // fp16 kernels: destination (and residual) hold fp32
     const float* src2; int src2_cs, up_c, up_W, up_H;   // fused upsample-on-read (v4): full-resolution W, H of the conv input
-    int lds_buf_floats;        // v2: floats per LDS stage buffer
-    int n_tiles_total;         // B * tiles_x * tiles_y (v2 blocks loop over tiles)
-    unsigned long long* debug; // diagnostics: per-wave phase stamps (6 words per wave), nullptr in product launches
+    int lds_buf_floats;        // fp16 what-if builds only (-DMI355_F16_DIAG): experiment flags; 0 in product launches
+    int n_tiles_total;         // B * tiles_x * tiles_y (persistent kernels walk tiles blockIdx.x, + gridDim.x, ...)
 };
 // A planned launch: kernel instance, grid, LDS bytes and kernel arguments.  Planning (tile / wave-arrangement
 // search) is done once per (op, shape) by the engine; run_conv only enqueues.
@@ -104,7 +103,6 @@ struct DecodeArgs {
     int B, A, nc, nkpt, kdim;
     float* pred;        // [B][A][no] anchor-major decoded tensor (xywh, scores, kpts), no = 4+nc+nkpt*kdim
     float2* best;       // [B][A] (best score, best class as float)
-    int tile0[4]; int tiles_per_image;   // filled by launch_decode
 };
 // full = also store the nc class scores into pred (raw-head entry point); NMS itself only needs box/kpts/best
 const char* launch_decode(const DecodeArgs& a, bool full, hipStream_t st);

@@ -1,0 +1,490 @@
+// Fused conv (1x1 / 3x3, stride 1 / 2) + bias + SiLU (+ residual) as an implicit GEMM on the CDNA4 fp32
+// matrix pipe (v_mfma_f32_16x16x4_f32: exact f32, a k-ordered fma chain, 64 FLOP/clk/SIMD).
+//
+// Replaces ultralytics/nn/modules/conv.py:Conv.forward_fuse (act(conv(x)) with the BN folded) and the
+// residual add of block.py:Bottleneck.forward, reached from /root/reference/model.py:38.
+//
+// GEMM view:  D[cout][pixel] = sum_{tap, ci} W[cout][tap][ci] * X[pixel @ tap][ci]
+//   MFMA A operand = weights  (row = cout,  k = input channel)   -> read from HBM/L2 in pre-packed
+//                                                                   fragment order (1 KiB per wave load)
+//   MFMA B operand = pixels   (col = pixel, k = input channel)   -> read from an LDS-staged NHWC halo tile
+//   so the accumulator of a lane holds 4 CONSECUTIVE couts of ONE pixel: the epilogue is one 16-byte store.
+// The k index inside a 16-channel block is permuted (MFMA step s covers channels {4g+s}) so that a lane's
+// four k-steps are one aligned float4 in both operands (ds_read_b128 / global_load_dwordx4).
+//
+// Block = 256 threads = 4 waves, arranged WP (along pixels) x WC (along couts); a wave owns PT pixel tiles
+// x CT cout tiles of 16x16.  The input tile (with halo) is staged through LDS in chunks of `ck` channels.
+//
+// This header holds the DEVICE code of the fp32 kernels; the instances the planner can pick are compiled in
+// conv_f32_k3s1.hip / conv_f32_k3s2.hip / conv_f32_k1.hip / conv_f32_pipe.hip (four translation units: they build in
+// parallel) and looked up through the pick_* functions of conv_f32_inst.h.  Host side (planner, weight packing):
+// conv_plan.hip.
+#pragma once
+#include "common.h"
+#include "detmath.h"
+#include <type_traits>
+#ifndef MI355_CONV_WAVES
+#define MI355_CONV_WAVES 3   // min waves per SIMD the register allocator must leave room for (4 blocks of 256 threads / CU = 4)
+#endif
+
+#pragma clang fp contract(off)
+
+namespace mi355 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float silu_f(float v) { return det_silu(v); }
+
+// bias + SiLU (+ residual) and the 16-byte stores: a lane holds 4 consecutive couts of one pixel per tile.
+// Two passes: all the ALU work first (16 independent SiLU chains per lane interleave freely), then the stores back to
+// back.
+template <int STRIDE, int PT, int CT, int WP>
+__device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x4 (&acc)[CT][PT], const f32x4 (&bias4)[CT], int lane, int wp,
+                                              int ct0, int b, int oy0, int ox0, int npix) {
+    if (a.act) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                f32x4 v = acc[ct][pt] + bias4[ct];
+                v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
+                acc[ct][pt] = v;
+            }
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = acc[ct][pt] + bias4[ct];
+    }
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int p = (wp * PT + pt) * 16 + (lane & 15);
+        const int pp = p < npix ? p : 0;
+        const int ly = (int)(((float)pp + 0.5f) * a.inv_TW);
+        const int lx = pp - ly * a.TW;
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        const bool ok = (p < npix) && (oy < a.Hout) && (ox < a.Wout);
+        const size_t po = ((size_t)b * a.Hout + oy) * a.Wout + ox;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = (ct0 + ct) * 16 + (lane >> 4) * 4;
+            if (!ok || c >= a.Cout) continue;
+            f32x4 v = acc[ct][pt];
+            float* d = a.dst + po * a.dst_cs + c;
+            if (c + 3 < a.Cout) {
+                if (a.res) v += *(const f32x4*)(a.res + po * a.res_cs + c);
+                *(f32x4*)d = v;
+            } else {
+                for (int i = 0; i < 4 && c + i < a.Cout; ++i) {
+                    float r = v[i];
+                    if (a.res) r += a.res[po * a.res_cs + c + i];
+                    d[i] = r;
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int STRIDE, int PT, int CT, int WP>
+__global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int WC = 4 / WP;
+    constexpr int TAPS = KS * KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave % WP, wc = wave / WP;
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
+    const int ct0 = (blockIdx.y * WC + wc) * CT;
+    const int npix = a.TW * a.TH;
+    int xoff[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        int p = (wp * PT + pt) * 16 + (lane & 15);
+        p = p < npix ? p : 0;
+        const int ly = (int)(((float)p + 0.5f) * a.inv_TW);
+        const int lx = p - ly * a.TW;
+        xoff[pt] = ((ly * STRIDE) * a.TWin + lx * STRIDE) * a.ldp + (lane >> 4) * 4;
+    }
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* srcb = a.src + (size_t)b * a.Hin * a.Win * a.src_cs;
+    // cout tiles beyond the last one re-read the last tile's weights (their outputs are discarded by the epilogue):
+    // no branch around the fragment loads, so hipcc keeps a counted s_waitcnt vmcnt(N) and the prefetch stays in flight
+    const float* wbase[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        wbase[ct] = a.wpk + (size_t)ctile * TAPS * a.cib * 256 + lane * 4;
+    }
+    // the bias of this lane's 4 couts per cout tile is fetched now (the load's L2 latency hides under the staging) and
+    // not in the epilogue, where it would sit on the block's critical path
+    f32x4 bias4[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        bias4[ct] = *(const f32x4*)(a.bias + ctile * 16 + (lane >> 4) * 4);
+    }
+    const int ck4m = (a.ck >> 2) - 1;
+    const int total_f4 = a.npix_in << a.ck4_shift;
+
+    for (int c0 = 0; c0 < a.Cin; c0 += a.ck) {
+        if (c0) __syncthreads();
+        // ---- stage the halo tile, channels [c0, c0+ck), zero-filled outside the image / beyond Cin ----
+        // Loads are issued in batches of 8 per thread BEFORE any of them is consumed (out-of-image / beyond-Cin slots
+        // read a zero page instead of branching), so one HBM/L2 latency is paid per batch, not per float4.
+        for (int base = 0; base < total_f4; base += 8 * 256) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int pix = idx >> a.ck4_shift, q = idx & ck4m;
+                const int iy = (int)(((float)pix + 0.5f) * a.inv_TWin);
+                const int ix = pix - iy * a.TWin;
+                const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + 4 * q;
+                const bool inb = idx < total_f4 && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && c < a.cin4;
+                const float* g = inb ? srcb + ((size_t)gy * a.Win + gx) * a.src_cs + c : a.zeros;
+                v[u] = *(const f32x4*)g;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                if (idx < total_f4) {
+                    const int pix = idx >> a.ck4_shift, q = idx & ck4m;
+                    *(f32x4*)(lds + pix * a.ldp + 4 * q) = v[u];
+                }
+            }
+        }
+        __syncthreads();
+        const int rem = a.Cin - c0;
+        const int nkk = ((rem < a.ck ? rem : a.ck) + 15) >> 4;
+        const int cib0 = c0 >> 4;
+        // canonical accumulation order of one output: 16-channel block (outer), tap, MFMA step s, k-group g.
+        // (block, tap) is flattened into one runtime loop of pipeline steps; all offsets advance as wave-uniform
+        // scalars.  Weight fragments come from L2 with 1-2k cycles of latency under load, so they are prefetched WD
+        // steps ahead through a ring of WD register sets; pixel fragments (LDS, ~100 cycles) one step ahead through two
+        // sets.  Both cursors CLAMP at the last step instead of guarding the loads: every load is unconditional, which
+        // is what lets hipcc keep counted s_waitcnt vmcnt(N) / lgkmcnt(N) instead of draining the queues.
+        constexpr int WD = (CT <= 2) ? 4 : 2;
+        const int n_it = nkk * TAPS;
+        const int wstep = a.cib * 256;
+        int w_it = 0, w_kw = 0, w_kh = 0, w_kk = 0, w_off = cib0 * 256;     // weight cursor: (tap*cib + cib0 + kk)*256 floats
+        int x_it = 0, x_kw = 0, x_kh = 0, x_kk = 0, x_off = 0;              // pixel cursor: (kh*TWin + kw)*ldp + kk*16 floats
+        f32x4 wf[WD][CT], xf[2][PT];
+        auto load_w = [&](f32x4* w) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(wbase[ct] + w_off);
+            if (w_it + 1 < n_it) {
+                ++w_it; ++w_kw; w_off += wstep;
+                if (w_kw == KS) {
+                    w_kw = 0; ++w_kh;
+                    if (w_kh == KS) { w_kh = 0; ++w_kk; w_off = (cib0 + w_kk) * 256; }
+                }
+            }
+        };
+        auto load_x = [&](f32x4* x) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) x[pt] = *(const f32x4*)__builtin_assume_aligned(lds + xoff[pt] + x_off, 16);
+            if (x_it + 1 < n_it) {
+                ++x_it; ++x_kw; x_off += a.ldp;
+                if (x_kw == KS) {
+                    x_kw = 0; ++x_kh; x_off += (a.TWin - KS) * a.ldp;
+                    if (x_kh == KS) { x_kh = 0; ++x_kk; x_off = x_kk * 16; }
+                }
+            }
+        };
+        auto mma = [&](const f32x4* w, const f32x4* x) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt)
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][s], x[pt][s], acc[ct][pt], 0, 0, 0);
+        };
+#pragma unroll
+        for (int j = 0; j < WD - 1; ++j) load_w(wf[j]);        // steps 0 .. WD-2
+        load_x(xf[0]);                                          // step 0
+        for (int it = 0; it < n_it; it += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                load_w(wf[(j + WD - 1) % WD]);                  // step it+j+WD-1 (clamped)
+                load_x(xf[(j + 1) & 1]);                        // step it+j+1    (clamped)
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + j < n_it) mma(wf[j % WD], xf[j & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    conv_epilogue<STRIDE, PT, CT, WP>(a, acc, bias4, lane, wp, ct0, b, oy0, ox0, npix);
+}
+
+// ---------------------------------------------------------------------------------------------- v3 (1x1 only)
+// Pointwise convs have no tap reuse, so staging pixels through LDS buys nothing: here every wave streams its pixel
+// fragments straight from global memory into the MFMA B-operand layout (lane (p, g) reads the 16 bytes of channels
+// 4g..4g+3 of pixel p: 64 contiguous bytes per pixel per 16-channel block), with a 4-deep register prefetch ring for
+// pixels (HBM latency) and weights (L2 latency).  No LDS, no barriers: waves drift apart and overlap each other's
+// epilogues.  Same canonical accumulation order as v1 (16-channel block outer, step s, k-group g).
+template <int PT, int CT>
+__global__ __launch_bounds__(256) void conv1x1_stream_f32(ConvKArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4;
+    const int total = a.Wout;                                        // flattened pixels (Hout == 1)
+    const int tile0 = ((int)blockIdx.x * 4 + wave) * PT;             // first 16-pixel tile of this wave
+    const int ct0 = (int)blockIdx.y * CT;
+    const float* xbase[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        int p = (tile0 + pt) * 16 + (lane & 15);
+        p = p < total ? p : total - 1;                               // clamp: results of padded pixels are never stored
+        xbase[pt] = a.src + (size_t)p * a.src_cs + 4 * g;
+    }
+    const float* wbase[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        wbase[ct] = a.wpk + (size_t)ctile * a.cib * 256 + lane * 4;
+    }
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 bias4[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        bias4[ct] = *(const f32x4*)(a.bias + ctile * 16 + g * 4);
+    }
+    constexpr int D = 4;                                             // prefetch depth (steps in flight: D-1)
+    const int n_it = a.cib;
+    // in the last 16-channel block the lanes whose 4 channels lie beyond round_up(Cin, 4) read zeros instead
+    const bool tail_oob = (n_it - 1) * 16 + 4 * g >= a.cin4;
+    f32x4 wf[D][CT], xf[D][PT];
+    int l_it = 0;
+    auto load = [&](f32x4* w, f32x4* x) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(wbase[ct] + l_it * 256);
+        const bool oob = tail_oob && (l_it == n_it - 1);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const float* px = oob ? a.zeros : xbase[pt] + l_it * 16;
+            x[pt] = *(const f32x4*)px;
+        }
+        if (l_it + 1 < n_it) ++l_it;                                 // clamp instead of guarding the loads
+    };
+    auto mma = [&](const f32x4* w, const f32x4* x) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][s], x[pt][s], acc[ct][pt], 0, 0, 0);
+    };
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) load(wf[j], xf[j]);
+    for (int it = 0; it < n_it; it += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            load(wf[(j + D - 1) % D], xf[(j + D - 1) % D]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + j < n_it) mma(wf[j], xf[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // epilogue (same math as conv_epilogue, flattened pixel index)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int p = (tile0 + pt) * 16 + (lane & 15);
+        const bool ok = p < total;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = (ct0 + ct) * 16 + g * 4;
+            if (!ok || c >= a.Cout) continue;
+            f32x4 v = acc[ct][pt] + bias4[ct];
+            if (a.act) {
+                v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
+            }
+            float* d = a.dst + (size_t)p * a.dst_cs + c;
+            if (c + 3 < a.Cout) {
+                if (a.res) v += *(const f32x4*)(a.res + (size_t)p * a.res_cs + c);
+                *(f32x4*)d = v;
+            } else {
+                for (int i = 0; i < 4 && c + i < a.Cout; ++i) {
+                    float r = v[i];
+                    if (a.res) r += a.res[(size_t)p * a.res_cs + c + i];
+                    d[i] = r;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- v4 (1x1 only)
+// Pointwise convs have a short K loop per staged chunk (Cin/16 steps), so in v1 the block spends as long waiting for its
+// activation loads as it spends on MFMAs.  v4 is a PERSISTENT, software-pipelined form of v1 for k = 1: the unit of work
+// is one (pixel tile, channel chunk) item; while the MFMAs of item i run from LDS, the global loads of item i+1 are
+// already in flight into registers, and the stores of the previous tile drain behind them.  vmcnt retires in order, so
+// the order of issue is what makes this work: the chunk's weight fragments (all of them: a 1x1 chunk has at most 4 k-blocks)
+// are requested BEFORE the prefetch, hence waiting for them never waits for the prefetch.
+// Same canonical accumulation order as v1 (16-channel block outer, step s, k-group g): same bits.
+template <int PT, int CT, int WP, bool SINGLE, int NKK>   // SINGLE: Cin fits one chunk -> every item ends a tile; NKK: k-blocks per chunk
+__global__ __launch_bounds__(256) void conv1x1_pipe_f32(ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int WC = 4 / WP, NV = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave % WP, wc = wave / WP, g = lane >> 4;
+    const int ct0 = (blockIdx.y * WC + wc) * CT;
+    const int P = a.TW, total = a.Wout;
+    const int sh = a.ck4_shift, ck4m = (a.ck >> 2) - 1, tile_v = P << sh;
+    const int nst = SINGLE ? 1 : (a.Cin + a.ck - 1) / a.ck;
+    const int n_tiles = a.n_tiles_total;
+    const int my_tiles = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int n_items = my_tiles * nst;
+    if (n_items == 0) return;
+
+    auto prefetch = [&](int item, f32x4 (&v)[NV]) {      // item >= n_items: every lane reads the zero page (loads stay unconditional)
+        const bool live = item < n_items;
+        const int ti = SINGLE ? item : item / nst;
+        const int p0 = ((int)blockIdx.x + ti * (int)gridDim.x) * P;
+        const int c0 = SINGLE ? 0 : (item - ti * nst) * a.ck;
+        // fused upsample: (image, row, column) of the tile's first pixel, once per item (uniform)
+        int ub = 0, uy = 0, ux = 0;
+        if (a.up_c) { const int hw = a.up_W * a.up_H; ub = p0 / hw; const int r = p0 - ub * hw; uy = r / a.up_W; ux = r - uy * a.up_W; }
+        int tq = tid; asm volatile("" : "+v"(tq));       // opaque: slot addresses recomputed per item instead of living in VGPRs
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int idx = u * 256 + tq;
+            const int pix = idx >> sh, q = idx & ck4m;
+            const int p = p0 + pix, c = c0 + 4 * q;
+            const bool inb = live && idx < tile_v && p < total && c < a.cin4;
+            const float* src = a.src + (size_t)p * a.src_cs + c;
+            if (c < a.up_c) {                            // channels of the upsampled operand: read pixel (y/2, x/2) of the half-size map
+                const int xx = ux + pix;                 // < W + tile: the quotient is tiny, the float form is exact
+                const int wr = (int)(((float)xx + 0.5f) * a.inv_TW);        // inv_TW = 1 / up_W for these launches
+                const int x = xx - wr * a.up_W, yy = uy + wr;
+                const int hr = (int)(((float)yy + 0.5f) * a.inv_TWin);      // inv_TWin = 1 / up_H; a tile may span several small images
+                const int y = yy - hr * a.up_H, b = ub + hr;
+                src = a.src2 + (((size_t)b * (a.up_H >> 1) + (y >> 1)) * (a.up_W >> 1) + (x >> 1)) * a.src2_cs + c;
+            }
+            if (!inb) src = a.zeros;
+            v[u] = *(const f32x4*)src;
+        }
+    };
+    auto commit = [&](const f32x4 (&v)[NV]) {
+        int tq = tid; asm volatile("" : "+v"(tq));
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int idx = u * 256 + tq;
+            if (idx < tile_v) *(f32x4*)(lds + (idx >> sh) * a.ldp + 4 * (idx & ck4m)) = v[u];
+        }
+    };
+    int xoff[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) xoff[pt] = ((wp * PT + pt) * 16 + (lane & 15)) * a.ldp + 4 * g;
+    const float* wbase[CT];
+    f32x4 bias4[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        wbase[ct] = a.wpk + (size_t)ctile * a.cib * 256 + lane * 4;
+        bias4[ct] = *(const f32x4*)(a.bias + ctile * 16 + g * 4);
+    }
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 pv[NV];
+    prefetch(0, pv);
+    commit(pv);
+    __syncthreads();
+    f32x4 w[NKK][CT];
+    auto load_w = [&](int item) {
+        const int st = SINGLE ? 0 : item % nst;
+        const int cib0 = (st * a.ck) >> 4;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int kb = cib0 + kk < a.cib ? cib0 + kk : a.cib - 1;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) w[kk][ct] = *(const f32x4*)(wbase[ct] + kb * 256);
+        }
+    };
+    load_w(0);
+    prefetch(1, pv);
+    for (int item = 0; item < n_items; ++item) {
+        const int st = SINGLE ? 0 : item % nst;
+        const int c0 = st * a.ck;
+        const int rem = a.Cin - c0;
+        const int nkk = ((rem < a.ck ? rem : a.ck) + 15) >> 4;
+        // ---- K loop of this item: pixel fragments one k-block ahead (two register sets), weights already in registers
+        f32x4 xf[2][PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) xf[0][pt] = *(const f32x4*)__builtin_assume_aligned(lds + xoff[pt], 16);
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int kn = (kk + 1 < nkk ? kk + 1 : nkk - 1) * 16;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) xf[(kk + 1) & 1][pt] = *(const f32x4*)__builtin_assume_aligned(lds + xoff[pt] + kn, 16);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk < nkk) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt)
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kk][ct][s], xf[kk & 1][pt][s], acc[ct][pt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                   // every wave is done reading this item's LDS image
+        commit(pv);                                        // item + 1 (zeros after the last one)
+        load_w(item + 1 < n_items ? item + 1 : item);      // requested before the stores and the next prefetch
+        if (SINGLE || st == nst - 1) {
+            // ---- epilogue of the tile that just finished (same math as conv_epilogue, flattened pixel index)
+            const int ti = SINGLE ? item : item / nst;
+            const int p0 = ((int)blockIdx.x + ti * (int)gridDim.x) * P;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int lp = (wp * PT + pt) * 16 + (lane & 15);
+                const int p = p0 + lp;
+                const bool ok = lp < P && p < total;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int c = (ct0 + ct) * 16 + g * 4;
+                    f32x4 v = acc[ct][pt] + bias4[ct];
+                    acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (!ok || c >= a.Cout) continue;
+                    if (a.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                    float* d = a.dst + (size_t)p * a.dst_cs + c;
+                    if (c + 3 < a.Cout) {
+                        if (a.res) v += *(const f32x4*)(a.res + (size_t)p * a.res_cs + c);
+                        *(f32x4*)d = v;
+                    } else {
+                        for (int i = 0; i < 4 && c + i < a.Cout; ++i) {
+                            float r = v[i];
+                            if (a.res) r += a.res[(size_t)p * a.res_cs + c + i];
+                            d[i] = r;
+                        }
+                    }
+                }
+            }
+        }
+        prefetch(item + 2, pv);
+        __syncthreads();                                   // item + 1's LDS image is complete
+    }
+}
+
+}  // namespace mi355

@@ -1,0 +1,19 @@
+// Lookup of the compiled fp32 conv kernel instances (device code: conv_f32.h).  One translation unit per kernel family so
+// that the library builds in parallel; the planner (conv_plan.hip) only sees these functions.
+#pragma once
+#include "common.h"
+
+namespace mi355 {
+
+typedef void (*KernelFn)(ConvKArgs);
+
+// conv_igemm_f32<KS, STRIDE, PT = (CT == 5 ? 3 : 4), CT, WP>: CT in 1..5, WP in {1, 2, 4}
+KernelFn pick_f32_k3s1(int CT, int WP);       // conv_f32_k3s1.hip
+KernelFn pick_f32_k3s2(int CT, int WP);       // conv_f32_k3s2.hip
+KernelFn pick_f32_k1(int CT, int WP);         // conv_f32_k1.hip
+// conv1x1_stream_f32<PT, CT>: CT in {1, 2, 4}, PT in {2, 4}
+KernelFn pick_f32_stream(int CT, int PT);     // conv_f32_k1.hip
+// conv1x1_pipe_f32<4, CT, WP, SINGLE, NKK>: CT in {1, 2, 4} (NKK 8: CT <= 2), WP in {1, 2, 4}; NKK = 8 when ck > 64
+KernelFn pick_f32_pipe(int CT, int WP, bool single, int ck);   // conv_f32_pipe.hip
+
+}  // namespace mi355

@@ -1,0 +1,242 @@
+// Host side of the conv kernels: weight packing into MFMA fragment order, the launch planner (tile shape x wave
+// arrangement x staged channels x kernel version per conv and shape; the engine times the best candidates) and run_conv.
+// Device code: conv_f32.h (instances: conv_f32_*.hip) and conv_igemm_f16.hip.
+#include "common.h"
+#include "conv_f32_inst.h"
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+namespace mi355 {
+
+size_t packed_weight_floats(int cout, int cin, int k) {
+    return (size_t)((cout + 15) / 16) * k * k * ((cin + 15) / 16) * 256;
+}
+
+void pack_conv_weights(const float* w, int cout, int cin, int k, float* out) {
+    const int nct = (cout + 15) / 16, cib = (cin + 15) / 16, taps = k * k;
+    for (int ct = 0; ct < nct; ++ct)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int cb = 0; cb < cib; ++cb) {
+                float* o = out + ((size_t)(ct * taps + tap) * cib + cb) * 256;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s = 0; s < 4; ++s) {
+                        const int co = ct * 16 + (lane & 15);
+                        const int ci = cb * 16 + 4 * (lane >> 4) + s;
+                        o[lane * 4 + s] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * taps + tap] : 0.f;
+                    }
+            }
+}
+
+namespace {
+
+struct Plan { int CT, WP, TW, TH, ck; size_t lds; double cost; int version; int buf_floats; int PT; };   // PT 0 = default (4, or 3 with CT 5)
+
+KernelFn pick_kernel(int ks, int stride, int CT, int WP) {
+    if (ks == 1 && stride == 1) return pick_f32_k1(CT, WP);
+    if (ks == 3 && stride == 1) return pick_f32_k3s1(CT, WP);
+    if (ks == 3 && stride == 2) return pick_f32_k3s2(CT, WP);
+    return nullptr;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+constexpr size_t LDS_SOFT = 40 * 1024, LDS_HARD = 64 * 1024;
+
+// Candidate launch plans for one conv: for every wave arrangement (CT, WC) the best output tile, with every
+// feasible staged-channel count.  Sorted by a static cost model; the engine may time the first few (autotune).
+std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, int stride, bool have_zero_page, bool half) {
+    static const int max_ct = env_int("MI355_MAX_CT", 5);          // tuning knobs (experiments only)
+    static const int min_wc = env_int("MI355_MIN_WC", 1);
+    std::vector<Plan> out;
+    const int cin16 = round_up(cin, 16);
+    // fp16 only: wave tiles of 8 pixel tiles (128 pixels x CT*16 couts) halve the weight bytes fetched per MFMA -- the f16
+    // MFMA retires a 1-KiB fragment pair in 16 cycles, so these kernels are bound by L1/L2 fragment traffic, not by the pipe
+    for (int PTsel = 0; PTsel <= (half ? 8 : 0); PTsel += 8)
+    for (int WC = 1; WC <= 4; WC *= 2)
+        for (int CT = 1; CT <= 5; ++CT) {
+            if (CT > max_ct || WC < min_wc) continue;
+            if (PTsel == 8 && CT > 4) continue;
+            const int WP = 4 / WC, PT = PTsel ? PTsel : (CT == 5 ? 3 : 4), P = WP * PT * 16;
+            const int cover = CT * WC, nblk = (n_ctiles + cover - 1) / cover;
+            if (cover >= 2 * n_ctiles && cover > CT) continue;          // more than half of the cout tiles would be padding
+            const double waste_c = (double)nblk * cover / n_ctiles;
+            // staged channels per chunk, in 4-byte units; the fp16 kernels (2 channels per unit) also get 128: their K loop
+            // is so short that the two barriers + pipeline refill per chunk show, above all in the 1x1 layers
+            for (int ck = half ? 128 : 64; ck >= 16; ck >>= 1) {
+                if (ck > cin16 && ck != 16) continue;
+                Plan best{}; best.cost = 1e30;
+                for (int TW = 1; TW <= P && TW <= W; ++TW) {
+                    int TH = P / TW; if (TH > H) TH = H;
+                    if (TH < 1) continue;
+                    const long tiles = (long)((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+                    const int THin = (TH - 1) * stride + ks, TWin = (TW - 1) * stride + ks;
+                    const size_t lds = (size_t)THin * TWin * (ck + 4) * 4;
+                    if (lds > LDS_HARD) continue;
+                    const double infl = waste_c * (double)tiles * P / ((double)W * H);
+                    const double halo = (double)THin * TWin / ((double)TH * TW * stride * stride);
+                    const int stages = (cin16 + ck - 1) / ck;
+                    double cost = infl * (1.0 + 0.03 * halo * nblk) * (1.0 + 0.04 * (stages - 1)) * (1.0 + 0.04 * (CT - 1))
+                                  + (lds > LDS_SOFT ? 0.15 : 0.0);
+                    if (cost < best.cost) best = Plan{CT, WP, TW, TH, ck, lds, cost, 1, 0, PTsel};
+                }
+                if (best.cost < 1e30) out.push_back(best);
+            }
+        }
+    if (ks == 1 && have_zero_page) {        // streaming pointwise kernel (needs the zero page as well): CT x PT register tiles
+        static const int use_v3 = env_int("MI355_CONV_V3", 1);
+        const int cts[3] = {1, 2, 4}, pts[2] = {2, 4};
+        for (int ci = 0; ci < 3 && use_v3; ++ci)
+            for (int pi = 0; pi < 2; ++pi) {
+                const int CT = cts[ci], PT = pts[pi];
+                if (CT > n_ctiles && CT != 1) continue;
+                const int nblk = (n_ctiles + CT - 1) / CT;
+                Plan p3{CT, 4, PT * 64, 1, 16, 0, 0.0, 3, PT, 0};
+                p3.cost = (double)nblk * CT / n_ctiles * (1.0 + 0.05 * nblk) * 0.9;
+                out.push_back(p3);
+            }
+    }
+    if (ks == 1 && have_zero_page) {   // persistent software-pipelined pointwise kernel (v4); ck in 4-byte units (fp16: 2 channels each)
+        static const int use_v4 = env_int("MI355_CONV_V4", 1);
+        const int wps[3] = {1, 2, 4}, cts[4] = {1, 2, 4, 3}, cks[4] = {128, 64, 32, 16};
+        for (int wi = 0; wi < 3 && use_v4; ++wi)
+            for (int ci = 0; ci < (half ? 4 : 3); ++ci)
+                for (int ki = 0; ki < 4; ++ki) {
+                    const int WP = wps[wi], WC = 4 / WP, CT = cts[ci], ck = cks[ki], P = WP * 64;
+                    const int cover = CT * WC, nblk = (n_ctiles + cover - 1) / cover;
+                    if (cover >= 2 * n_ctiles && cover > CT) continue;
+                    if (ck > cin16 && ck != 16) continue;
+                    if (P * ck / 4 > 2048) continue;                       // 8 prefetch registers (float4) per thread
+                    if (ck > 64 && CT > (half ? 3 : 2)) continue;          // a chunk's weights live in registers: 8 k-blocks x CT fragments
+                    const size_t lds = (size_t)P * (ck + 4) * 4;
+                    const int stages = (cin16 + ck - 1) / ck;
+                    Plan p4{CT, WP, P, 1, ck, lds, 0.0, 4, 0, 0};
+                    p4.cost = (double)nblk * cover / n_ctiles * (1.0 + 0.03 * (stages - 1)) * (1.0 + 0.02 * nblk) * 0.8;
+                    out.push_back(p4);
+                }
+    }
+    std::sort(out.begin(), out.end(), [](const Plan& a, const Plan& b) { return a.cost < b.cost; });
+    return out;
+}
+
+}  // namespace
+
+static const char* check_args(const ConvArgs& c) {
+    if (!((c.k == 1 && c.stride == 1) || (c.k == 3 && (c.stride == 1 || c.stride == 2))))
+        return "conv: only 1x1/s1, 3x3/s1 and 3x3/s2 are supported";
+    if (c.dtype == 1) {     // fp16 storage: 16-byte source vectors = 8 halfs, 8-byte (or fp32 16-byte) destination vectors
+        if ((c.src_cs & 7) || (c.dst_cs & 3) || (c.res && (c.res_cs & 3))) return "conv(f16): channel strides must be multiples of 8 (src) / 4 (dst)";
+        if (((uintptr_t)c.src | (uintptr_t)c.wpk | (uintptr_t)c.bias) & 15) return "conv(f16): src / weight / bias pointers must be 16-byte aligned";
+        const bool wide = !c.out_f32 && conv_f16_pairs(c.Cout);          // 16-byte fp16 stores of 8 consecutive couts
+        if (((uintptr_t)c.dst | (uintptr_t)c.res) & ((c.out_f32 || wide) ? 15 : 7)) return "conv(f16): dst / residual pointers are misaligned";
+        if (wide && ((c.dst_cs & 7) || (c.res && (c.res_cs & 7)))) return "conv(f16): dst / residual strides must be multiples of 8";
+        if (!c.zeros) return "conv: zero page missing";
+        return nullptr;
+    }
+    if ((c.src_cs & 3) || (c.dst_cs & 3) || (c.res && (c.res_cs & 3))) return "conv: channel strides must be multiples of 4";
+    if (((uintptr_t)c.src | (uintptr_t)c.dst | (uintptr_t)c.res | (uintptr_t)c.wpk | (uintptr_t)c.bias) & 15)
+        return "conv: pointers must be 16-byte aligned";
+    if (!c.zeros) return "conv: zero page missing";
+    return nullptr;
+}
+
+static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* out) {
+    ConvKArgs a{};
+    a.src = c.src; a.dst = c.dst; a.res = c.res; a.wpk = c.wpk; a.bias = c.bias;
+    a.src_cs = c.src_cs; a.dst_cs = c.dst_cs; a.res_cs = c.res_cs;
+    a.Cin = c.Cin; a.Cout = c.Cout; a.pad = c.pad; a.act = c.act;
+    const bool half = c.dtype == 1;
+    a.cib = half ? (c.Cin + 31) / 32 : (c.Cin + 15) / 16; a.n_ctiles = (c.Cout + 15) / 16;
+    a.cin4 = half ? round_up(c.Cin, 8) : round_up(c.Cin, 4);       // channels covered by whole 16-byte vectors
+    a.out_f32 = c.out_f32;
+    a.src2 = c.src2; a.src2_cs = c.src2_cs; a.up_c = c.src2 ? c.up_c : 0; a.up_W = c.Win; a.up_H = c.Hin;
+    int B = c.B;
+    if (c.k == 1) {   // pointwise: flatten batch and space into one row of pixels
+        a.Hin = 1; a.Win = c.B * c.Hin * c.Win; a.Hout = 1; a.Wout = a.Win; B = 1;
+    } else {
+        a.Hin = c.Hin; a.Win = c.Win; a.Hout = c.Hout; a.Wout = c.Wout;
+    }
+    KernelFn fn = half ? (p.version == 4 ? (KernelFn)pick_conv_pipe_f16(p.CT, p.WP, (c.Cin + 1) / 2 <= p.ck, p.ck > 64)
+                                         : (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.version == 3 ? p.buf_floats : p.PT))
+                       : (p.version == 3 ? pick_f32_stream(p.CT, p.buf_floats)
+                          : p.version == 4 ? pick_f32_pipe(p.CT, p.WP, c.Cin <= p.ck, p.ck) : pick_kernel(c.k, c.stride, p.CT, p.WP));
+    if (!fn) return "conv: no kernel instance";
+    a.zeros = c.zeros; a.lds_buf_floats = p.buf_floats;
+    if (half && p.version == 4) a.lds_buf_floats = 0;
+    if (half && p.version == 1) { static const int ex = env_int("MI355_F16_EXP", 0); a.lds_buf_floats = ex; }
+    a.TW = p.TW; a.TH = p.TH;
+    a.tiles_x = (a.Wout + p.TW - 1) / p.TW; a.tiles_y = (a.Hout + p.TH - 1) / p.TH;
+    a.TWin = (p.TW - 1) * c.stride + c.k;
+    const int THin = (p.TH - 1) * c.stride + c.k;
+    a.npix_in = a.TWin * THin;
+    a.inv_TW = 1.0f / (float)p.TW; a.inv_TWin = 1.0f / (float)a.TWin;
+    if (p.version == 4 && a.up_c) { a.inv_TW = 1.0f / (float)c.Win; a.inv_TWin = 1.0f / (float)c.Hin; }   // v4 has no other use for them
+    // plans count staged channels in 4-byte units; the fp16 kernels stage twice as many channels in the same bytes
+    a.ck = half ? 2 * p.ck : p.ck; a.ldp = half ? a.ck + 8 : a.ck + 4;
+    a.ck4_shift = (p.ck == 128 ? 5 : p.ck == 64 ? 4 : p.ck == 32 ? 3 : 2);
+    const int WC = 4 / p.WP;
+    out->fn = (const void*)fn;
+    a.n_tiles_total = (int)((long)B * a.tiles_x * a.tiles_y);
+    out->grid_x = (unsigned)a.n_tiles_total;
+    if (p.version == 4) {
+        // persistent: exactly as many blocks as stay resident (asked of the runtime: registers, LDS), each walks tiles
+        // blockIdx.x, + gridDim.x, ...; blocks that had to queue behind others would leave CUs half empty at the end
+        const int gy = std::max(1, (a.n_ctiles + p.CT * (4 / p.WP) - 1) / (p.CT * (4 / p.WP)));
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, 256, p.lds) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            per_cu = std::max(1, std::min(3, (int)((size_t)(160 * 1024) / std::max<size_t>(p.lds, 1))));
+        }
+        out->grid_x = std::min(out->grid_x, (unsigned)std::max(1, 256 * per_cu / gy));
+    }
+    out->grid_y = (unsigned)((a.n_ctiles + p.CT * WC - 1) / (p.CT * WC));
+    out->lds = p.lds;
+    out->a = a;
+    out->CT = p.CT; out->WP = p.WP; out->version = p.version;
+    out->PT = p.version == 3 ? p.buf_floats : (p.PT ? p.PT : (p.CT == 5 ? 3 : 4)); out->threads = 256;
+    if (p.version == 3) {          // streaming 1x1: block = 4 waves x PT pixel tiles, grid.y over cout blocks of CT tiles
+        const int PT = p.buf_floats;
+        out->grid_x = (unsigned)((a.Wout + 4 * PT * 16 - 1) / (4 * PT * 16));
+        out->grid_y = (unsigned)((a.n_ctiles + p.CT - 1) / p.CT);
+        out->lds = 0;
+        out->a.tiles_x = (int)out->grid_x;
+    }
+    out->flops = 2.0 * c.B * c.Hout * c.Wout * (double)c.Cout * c.Cin * c.k * c.k;
+    return nullptr;
+}
+
+// all candidate launches for one conv, best static guess first
+const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out) {
+    if (const char* e = check_args(c)) return e;
+    const int H = c.k == 1 ? 1 : c.Hout, W = c.k == 1 ? c.B * c.Hout * c.Wout : c.Wout;
+    const bool half = c.dtype == 1;
+    const std::vector<Plan> plans = enumerate_plans(H, W, (c.Cout + 15) / 16, half ? (c.Cin + 1) / 2 : c.Cin, c.k, c.stride,
+                                                    c.zeros != nullptr, half);
+    if (plans.empty()) return "conv: no launch plan fits in LDS";
+    for (const Plan& p : plans) {
+        if (c.src2 && p.version != 4) continue;       // upsample-on-read exists in the v4 kernels only
+        ConvLaunch l{};
+        if (const char* e = build_launch(c, p, &l)) return e;
+        out->push_back(l);
+    }
+    if (out->empty()) return "conv: no launch plan supports the fused upsample";
+    return nullptr;
+}
+
+const char* plan_conv(const ConvArgs& c, ConvLaunch* out) {
+    std::vector<ConvLaunch> v;
+    if (const char* e = plan_conv_candidates(c, &v)) return e;
+    *out = v[0];
+    return nullptr;
+}
+
+const char* run_conv(const ConvLaunch& l, hipStream_t st) {
+    hipLaunchKernelGGL((KernelFn)l.fn, dim3(l.grid_x, l.grid_y), dim3(l.threads), l.lds, st, l.a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+}  // namespace mi355

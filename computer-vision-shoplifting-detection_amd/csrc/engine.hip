@@ -257,7 +257,7 @@ static int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
         std::memcpy(tmp.data(), b, (size_t)c.cout * 4);
         HIPCHK(hipMalloc(&d.bias, bn * 4));
         HIPCHK(hipMemcpy(d.bias, tmp.data(), bn * 4, hipMemcpyHostToDevice));
-        if (c.cin == 3) {                      // stem: raw OIHW, read by stem_conv_u8
+        if (c.cin == 3) {                      // stem: raw OIHW, read by stem_mfma_u8
             HIPCHK(hipMalloc(&d.w_raw, wn * 4));
             HIPCHK(hipMemcpy(d.w_raw, w, wn * 4, hipMemcpyHostToDevice));
         } else if (h->half) {
@@ -571,8 +571,8 @@ static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, c
                 } else {
                     l.a.n_tiles_total = (int)((long)nb * l.a.tiles_x * l.a.tiles_y);
                 }
-                // v1: one block per tile; v2 (persistent): keep the planned grid unless fewer tiles exist
-                l.grid_x = (l.version == 2 || l.version == 4 || l.version == 5) ? std::min(l.grid_x, (unsigned)l.a.n_tiles_total) : (unsigned)l.a.n_tiles_total;
+                // v1: one block per tile; v4 (persistent): keep the planned grid unless fewer tiles exist
+                l.grid_x = l.version == 4 ? std::min(l.grid_x, (unsigned)l.a.n_tiles_total) : (unsigned)l.a.n_tiles_total;
             }
             if (pf.begin(K_CONV)) return fail(MI355_EHIP, "event");
             KCHK(run_conv(l, st));
@@ -1108,27 +1108,6 @@ static int bench_conv2d_impl(int device_id, int n, int h, int w, int cin, int co
     if (plan_desc && plan_desc_len > 0)
         snprintf(plan_desc, plan_desc_len, "v%d CT%d PT%d WP%d tile %dx%d ck%d lds %zu grid %ux%u", l.version, l.CT, l.PT, l.WP, l.a.TW, l.a.TH, l.a.ck,
                  l.lds, l.grid_x, l.grid_y);
-    if (getenv("MI355_STAMPS") && l.version == 1 && !half) {
-        // diagnostic: one stamped launch; prints the mean per-wave phase durations (shader cycles)
-        ConvLaunch ls = l;
-        const size_t nw = (size_t)l.grid_x * l.grid_y * 4;
-        unsigned long long* d_dbg;
-        HIPCHK(dm.alloc(&d_dbg, nw * 6 * 8));
-        HIPCHK(hipMemset(d_dbg, 0, nw * 6 * 8));
-        ls.a.debug = d_dbg;
-        KCHK(run_conv(l, nullptr)); KCHK(run_conv(ls, nullptr));
-        HIPCHK(hipDeviceSynchronize());
-        std::vector<unsigned long long> hd(nw * 6);
-        HIPCHK(hipMemcpy(hd.data(), d_dbg, nw * 6 * 8, hipMemcpyDeviceToHost));
-        double st = 0, lp = 0, ep = 0, tot = 0, ld = 0, alu = 0, real = 0;
-        for (size_t i = 0; i < nw; ++i) {
-            st += hd[i * 6 + 1]; lp += hd[i * 6 + 2]; ep += hd[i * 6 + 3]; tot += hd[i * 6 + 4];
-            ld += (double)(hd[i * 6 + 0] >> 24); alu += (double)(hd[i * 6 + 0] & 0xffffff); real += (double)hd[i * 6 + 5];
-        }
-        fprintf(stderr, "[stamps] waves %zu  mean cycles per wave: staging %.0f (own loads+LDS writes landed after %.0f, rest = barrier wait)  "
-                        "k-loop %.0f  epilogue %.0f (ALU pass %.0f, rest = store pass incl. acks)  lifetime %.0f  | shader clock %.2f GHz\n",
-                nw, st / nw, ld / nw, lp / nw, ep / nw, alu / nw, tot / nw, tot / real * 0.1);
-    }
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     for (int i = 0; i < 2; ++i) KCHK(run_conv(l, nullptr));

@@ -17,96 +17,15 @@ __device__ __forceinline__ float silu_m(float v) { return det_silu(v); }
 // ---------------------------------------------------------------------------------------------- stem
 // model.0: Conv(3 -> Cout, k, s) on the letterboxed uint8 BGR frame.  Fuses the rest of
 // engine/predictor.py:preprocess (BGR->RGB, uint8 -> float32, /255 via an exact 256-entry table) into the
-// conv read, so the 4.9 MB/frame fp32 input tensor never exists.  One lane = one output pixel x 4 couts
-// (16-byte store); the Cout/4 lanes of a pixel sit next to each other so a wave writes contiguous memory.
-// Direct conv on the vector ALUs: K = 27 (or 108) is far too shallow for the matrix pipe and the layer is
-// HBM-write bound (16-48 floats out per 27 bytes in).
+// conv read, so the 4.9 MB/frame fp32 input tensor never exists.  The layer is HBM-write bound (16-48 floats out per
+// 27 bytes in) and, because of its bit-exact SiLU, issue-bound.
 constexpr int STEM_TO = 16;        // output tile 16 x 16 pixels per block
 
-template <int KS>
-__global__ __launch_bounds__(256) void stem_conv_u8(StemArgs a) {
-    // LDS: weights [KS*KS*3][Cout4] | lut[256] | input tile [TIN][TIN][3] already converted to float (0 outside the image:
-    // fmaf(0, w, acc) == acc exactly, so zero-filling equals skipping the tap)
-    extern __shared__ __attribute__((aligned(16))) float wl[];
-    const int cq = (a.Cout + 3) >> 2, cout4 = cq << 2;
-    const int TIN = (STEM_TO - 1) * a.stride + KS;
-    float* lut = wl + KS * KS * 3 * cout4;
-    float* tin = lut + 256;
-    for (int i = threadIdx.x; i < KS * KS * 3 * cout4; i += 256) {
-        const int co = i % cout4, r = i / cout4;       // r = tap*3 + byte channel (B,G,R)
-        const int cb = r % 3, tap = r / 3;
-        // byte channel cb (0=B,1=G,2=R) feeds model channel 2-cb (im[..., ::-1])
-        wl[i] = co < a.Cout ? a.w[((size_t)co * 3 + (2 - cb)) * (KS * KS) + tap] : 0.f;
-    }
-    lut[threadIdx.x] = a.lut[threadIdx.x];
-    const int tiles_x = (a.Wout + STEM_TO - 1) / STEM_TO, tiles_y = (a.Hout + STEM_TO - 1) / STEM_TO;
-    int t = blockIdx.x;
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y;
-    const int b = t / tiles_y;
-    const int oy0 = ty * STEM_TO, ox0 = tx * STEM_TO;
-    const int iy0 = oy0 * a.stride - a.pad, ix0 = ox0 * a.stride - a.pad;
-    const uint8_t* img = a.img + (size_t)b * a.H * a.W * 3;
-    __syncthreads();
-    for (int i = threadIdx.x; i < TIN * TIN * 3; i += 256) {
-        const int c = i % 3, p = i / 3;
-        const int ix = p % TIN, iy = p / TIN;
-        const int gy = iy0 + iy, gx = ix0 + ix;
-        float v = 0.f;
-        if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) v = lut[img[((size_t)gy * a.W + gx) * 3 + c]];
-        tin[i] = v;
-    }
-    __syncthreads();
-    for (int item = threadIdx.x; item < STEM_TO * STEM_TO * cq; item += 256) {
-        const int q = item % cq, lp = item / cq;
-        const int lx = lp % STEM_TO, ly = lp / STEM_TO;
-        const int oy = oy0 + ly, ox = ox0 + lx;
-        if (oy >= a.Hout || ox >= a.Wout) continue;
-        const float* xin = tin + ((ly * a.stride) * TIN + lx * a.stride) * 3;
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kh = 0; kh < KS; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < KS; ++kw) {
-                const float* wr = wl + ((kh * KS + kw) * 3) * cout4 + 4 * q;
-#pragma unroll
-                for (int cb = 0; cb < 3; ++cb) {
-                    const float v = xin[(kh * TIN + kw) * 3 + cb];
-                    const f32x4 w4 = *(const f32x4*)(wr + cb * cout4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(v, w4[j], acc[j]);   // canonical chain: kh, kw, (B,G,R)
-                }
-            }
-        const int c = 4 * q;
-        if (a.out_half) {
-            _Float16* dh = (_Float16*)a.dst + (((size_t)b * a.Hout + oy) * a.Wout + ox) * a.dst_cs + c;
-            if (c + 3 < a.Cout) {
-                f16x4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (_Float16)silu_m(acc[j] + a.bias[c + j]);
-                *(f16x4*)dh = o;
-            } else {
-                for (int j = 0; j < 4 && c + j < a.Cout; ++j) dh[j] = (_Float16)silu_m(acc[j] + a.bias[c + j]);
-            }
-            continue;
-        }
-        float* d = a.dst + (((size_t)b * a.Hout + oy) * a.Wout + ox) * a.dst_cs + c;
-        if (c + 3 < a.Cout) {
-            f32x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = silu_m(acc[j] + a.bias[c + j]);
-            *(f32x4*)d = o;
-        } else {
-            for (int j = 0; j < 4 && c + j < a.Cout; ++j) d[j] = silu_m(acc[j] + a.bias[c + j]);
-        }
-    }
-}
-
-// The same layer on the fp32 matrix pipe: an implicit GEMM with K = KS*KS*3 (27 or 108, padded to a multiple of 4) whose
+// An implicit GEMM on the fp32 matrix pipe with K = KS*KS*3 (27 or 108, padded to a multiple of 4) whose
 // B operand is gathered from the LDS input tile through a per-lane offset table (im2col on the fly, one ds_read_b32 per
 // MFMA operand).  k runs (kh, kw, byte channel B,G,R) ascending and v_mfma_f32_16x16x4_f32 chains its 4 k-values in
-// order, so the sum is the SAME fma chain as stem_conv_u8 / the oracle's det_stem -- bit for bit -- at 4-5x the rate
-// of the vector-ALU kernel (which peaked at ~15 TFLOP/s, below both the HBM and the matrix roof of this layer).
+// order, so the sum is the fma chain of the oracle's det_stem -- bit for bit -- at 4-5x the rate of a vector-ALU direct
+// conv (measured in round 1: ~15 TFLOP/s, below both the HBM and the matrix roof of this layer).
 // Block = 256 threads = 4 waves, output tile 16 x 16: wave w owns pixel rows 4w..4w+3 (4 MFMA pixel tiles) x CT cout tiles.
 // Input bytes are fetched as aligned dwords (4 pixels' worth of bytes per load) instead of one byte per lane.
 template <int KS, int CT>
@@ -267,21 +186,10 @@ static bool launch_stem_mfma(const StemArgs& a, unsigned grid, hipStream_t st) {
 
 const char* launch_stem(const StemArgs& a, hipStream_t st) {
     if (a.k != 3 && a.k != 6) return "stem: only 3x3 and 6x6 stems are supported";
+    if (a.dst_cs & 3) return "stem: destination pixel stride must be a multiple of 4 elements";
     const unsigned grid = (unsigned)((long)a.B * ((a.Wout + STEM_TO - 1) / STEM_TO) * ((a.Hout + STEM_TO - 1) / STEM_TO));
-    static const bool use_mfma = []() { const char* e = getenv("MI355_STEM_MFMA"); return e ? atoi(e) != 0 : true; }();
-    if (use_mfma && (a.dst_cs & 3) == 0) {
-        const bool ok = a.k == 3 ? launch_stem_mfma<3>(a, grid, st) : launch_stem_mfma<6>(a, grid, st);
-        if (ok) {
-            hipError_t e = hipGetLastError();
-            return e == hipSuccess ? nullptr : hipGetErrorString(e);
-        }
-    }
-    const int cq = (a.Cout + 3) / 4;
-    const int tin = (STEM_TO - 1) * a.stride + a.k;
-    const size_t lds = ((size_t)a.k * a.k * 3 * cq * 4 + 256 + (size_t)tin * tin * 3) * sizeof(float);
-    if (lds > 64 * 1024) return "stem: tile does not fit in LDS";
-    if (a.k == 3) hipLaunchKernelGGL(stem_conv_u8<3>, dim3(grid), dim3(256), lds, st, a);
-    else          hipLaunchKernelGGL(stem_conv_u8<6>, dim3(grid), dim3(256), lds, st, a);
+    const bool ok = a.k == 3 ? launch_stem_mfma<3>(a, grid, st) : launch_stem_mfma<6>(a, grid, st);
+    if (!ok) return "stem: more than 80 output channels or a tile that does not fit in LDS";
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

@@ -17,262 +17,14 @@ namespace mi355 {
 
 // ---------------------------------------------------------------------------------------------- decode
 // Reads the raw head maps (NHWC, per level: 64 box logits | nc class logits | nk kpts) and writes, per anchor, the
-// decoded row [4 box | nc scores | nk kpts] (anchor-major) plus (best score, best class).
-// One lane owns one anchor and evaluates it sequentially (the canonical operation order), but all global traffic
-// is coalesced: a 128-anchor tile of one level is contiguous in NHWC memory, so it is staged through LDS
-// (row pitch odd -> conflict-free per-lane row walks).  FULL = also store the nc sigmoid scores (only the
-// raw-head parity entry point needs them: NMS reads box, keypoints and `best` only), which cuts the kernel's
-// HBM writes from 86 to 6 floats per anchor for an 80-class detector.
-constexpr int DEC_T = 128;
-
-template <bool FULL>
-__global__ __launch_bounds__(DEC_T) void decode_kernel(DecodeArgs a, int pw) {
-    extern __shared__ float tile[];                     // [DEC_T][pw], pw odd and >= max(64, nc, nk)
-    const int tid = threadIdx.x;
-    // block -> (image, level, tile of 128 anchors inside the level)
-    int blk = blockIdx.x;
-    const int tiles_per_img = a.tiles_per_image;
-    const int b = blk / tiles_per_img;
-    blk -= b * tiles_per_img;
-    int l = 0;
-#pragma unroll
-    for (int j = 1; j < 4; ++j)
-        if (j < a.n_levels && blk >= a.tile0[j]) l = j;
-    const HeadLevelArgs lv = a.lv[l];
-    const int hw = lv.H * lv.W;
-    const int li0 = (blk - a.tile0[l]) * DEC_T;         // first anchor of this tile within the level
-    const int n_here = min(DEC_T, hw - li0);
-    const float* src = lv.buf + ((size_t)b * hw + li0) * lv.cs;     // n_here consecutive pixels, lv.cs floats each
-    const int nk = a.nkpt * a.kdim, no = 4 + a.nc + nk;
-    const int li = li0 + tid;
-    const bool live = tid < n_here;
-    const int y = live ? li / lv.W : 0, x = live ? li - y * lv.W : 0;
-    const float ax = (float)x + 0.5f, ay = (float)y + 0.5f, st = (float)lv.stride;
-    const size_t row = (size_t)b * a.A + lv.anchor0 + li;
-    float* out = a.pred + row * no;
-
-    // ---- box: 64 logits per anchor
-    for (int i = tid; i < n_here * 16; i += DEC_T) {
-        const int r = i >> 4, q = i & 15;
-        const float4 v = *(const float4*)(src + (size_t)r * lv.cs + lv.box_off + 4 * q);
-        float* t = tile + r * pw + 4 * q;
-        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
-    }
-    __syncthreads();
-    if (live) {
-        const float* t = tile + tid * pw;
-        float dist[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float v[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = t[16 * s + j];
-            float m = v[0];
-#pragma unroll
-            for (int j = 1; j < 16; ++j) m = fmaxf(m, v[j]);
-            float sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { v[j] = det_expf(v[j] - m); sum += v[j]; }
-            float d = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) d += (v[j] / sum) * (float)j;
-            dist[s] = d;
-        }
-        const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
-        float4 o;
-        o.x = ((x1 + x2) / 2.0f) * st;
-        o.y = ((y1 + y2) / 2.0f) * st;
-        o.z = (x2 - x1) * st;
-        o.w = (y2 - y1) * st;
-        if ((no & 3) == 0) *(float4*)out = o;           // rows are 16-byte aligned when 4 + nc + nk is a multiple of 4
-        else { out[0] = o.x; out[1] = o.y; out[2] = o.z; out[3] = o.w; }
-    }
-    __syncthreads();
-    // ---- class scores
-    for (int i = tid; i < n_here * a.nc; i += DEC_T) {
-        const int r = i / a.nc, c = i - r * a.nc;
-        tile[r * pw + c] = src[(size_t)r * lv.cs + lv.cls_off + c];
-    }
-    __syncthreads();
-    if (live) {
-        float* t = tile + tid * pw;
-        float best = -1.f; int bi = 0;
-        for (int c = 0; c < a.nc; ++c) {
-            const float s = det_sigmoid(t[c]);
-            if (FULL) t[c] = s;
-            if (s > best) { best = s; bi = c; }
-        }
-        a.best[row] = make_float2(best, (float)bi);
-    }
-    if (FULL) {
-        __syncthreads();
-        float* o = a.pred + ((size_t)b * a.A + lv.anchor0 + li0) * no;
-        for (int i = tid; i < n_here * a.nc; i += DEC_T) {
-            const int r = i / a.nc, c = i - r * a.nc;
-            o[(size_t)r * no + 4 + c] = tile[r * pw + c];
-        }
-    }
-    if (nk == 0) return;
-    // ---- keypoints
-    __syncthreads();
-    for (int i = tid; i < n_here * nk; i += DEC_T) {
-        const int r = i / nk, c = i - r * nk;
-        tile[r * pw + c] = src[(size_t)r * lv.cs + lv.kpt_off + c];
-    }
-    __syncthreads();
-    if (live) {
-        float* t = tile + tid * pw;
-        for (int k = 0; k < a.nkpt; ++k) {
-            float* kp = t + k * a.kdim;
-            kp[0] = (kp[0] * 2.0f + (ax - 0.5f)) * st;
-            kp[1] = (kp[1] * 2.0f + (ay - 0.5f)) * st;
-            if (a.kdim == 3) kp[2] = det_sigmoid(kp[2]);
-        }
-    }
-    __syncthreads();
-    {
-        float* o = a.pred + ((size_t)b * a.A + lv.anchor0 + li0) * no;
-        for (int i = tid; i < n_here * nk; i += DEC_T) {
-            const int r = i / nk, c = i - r * nk;
-            o[(size_t)r * no + 4 + a.nc + c] = tile[r * pw + c];
-        }
-    }
-}
-
-// Fast path (4 + nc + nk a multiple of 4, i.e. every standard detect / pose head): same per-anchor arithmetic, but
-// all LDS traffic is 16-byte wide and conflict-free (row pitch = an ODD number of 16-byte slots) and the tile copies use
-// a fixed 16-lanes-per-anchor mapping, so there is no integer division per element.
-template <bool FULL>
-__global__ __launch_bounds__(DEC_T) void decode_kernel_v2(DecodeArgs a, int ps) {      // ps = row pitch in float4 slots (odd)
-    extern __shared__ __attribute__((aligned(16))) float tile[];
-    const int tid = threadIdx.x, sub = tid & 15, rgrp = tid >> 4;                     // 8 row groups of 16 lanes
-    int blk = blockIdx.x;
-    const int b = blk / a.tiles_per_image;
-    blk -= b * a.tiles_per_image;
-    int l = 0;
-#pragma unroll
-    for (int j = 1; j < 4; ++j)
-        if (j < a.n_levels && blk >= a.tile0[j]) l = j;
-    const HeadLevelArgs lv = a.lv[l];
-    const int hw = lv.H * lv.W;
-    const int li0 = (blk - a.tile0[l]) * DEC_T;
-    const int n_here = min(DEC_T, hw - li0);
-    const float* src = lv.buf + ((size_t)b * hw + li0) * lv.cs;
-    const int nk = a.nkpt * a.kdim, no = 4 + a.nc + nk;
-    const int ncq = (a.nc + 3) >> 2, nkq = (nk + 3) >> 2;
-    const int pw = ps * 4;
-    const int li = li0 + tid;
-    const bool live = tid < n_here;
-    const int y = live ? li / lv.W : 0, x = live ? li - y * lv.W : 0;
-    const float ax = (float)x + 0.5f, ay = (float)y + 0.5f, st = (float)lv.stride;
-    const size_t row = (size_t)b * a.A + lv.anchor0 + li;
-    float* out = a.pred + row * no;
-    float* out0 = a.pred + ((size_t)b * a.A + lv.anchor0 + li0) * no;
-
-    // ---- box: 16 float4 per anchor
-    for (int r = rgrp; r < n_here; r += DEC_T / 16)
-        *(float4*)(tile + r * pw + 4 * sub) = *(const float4*)(src + (size_t)r * lv.cs + lv.box_off + 4 * sub);
-    __syncthreads();
-    if (live) {
-        const float4* t = (const float4*)(tile + tid * pw);
-        float dist[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float v[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const float4 q4 = t[4 * s + j]; v[4 * j] = q4.x; v[4 * j + 1] = q4.y; v[4 * j + 2] = q4.z; v[4 * j + 3] = q4.w; }
-            float m = v[0];
-#pragma unroll
-            for (int j = 1; j < 16; ++j) m = fmaxf(m, v[j]);
-            float sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { v[j] = det_expf(v[j] - m); sum += v[j]; }
-            float d = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) d += (v[j] / sum) * (float)j;
-            dist[s] = d;
-        }
-        const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
-        float4 o;
-        o.x = ((x1 + x2) / 2.0f) * st;
-        o.y = ((y1 + y2) / 2.0f) * st;
-        o.z = (x2 - x1) * st;
-        o.w = (y2 - y1) * st;
-        *(float4*)out = o;
-    }
-    __syncthreads();
-    // ---- class scores: ncq float4 per anchor (the slice is padded to a multiple of 4 channels in the head buffer)
-    for (int r = rgrp; r < n_here; r += DEC_T / 16)
-        for (int q = sub; q < ncq; q += 16)
-            *(float4*)(tile + r * pw + 4 * q) = *(const float4*)(src + (size_t)r * lv.cs + lv.cls_off + 4 * q);
-    __syncthreads();
-    if (live) {
-        float* t = tile + tid * pw;
-        float best = -1.f; int bi = 0;
-        // NMS only needs max_c sigmoid(logit_c) and its FIRST argmax.  sigmoid is monotone, so only classes whose logit is
-        // within a hair of the largest one can hold or tie the maximum: evaluate the (35-instruction, bit-exact) sigmoid for
-        // those alone -- 1-2 classes instead of 80.  The window is exact, not heuristic: up to 11 the fp32 sigmoid still
-        // separates logits 0.01 apart by >= 2.8 ulp (det_expf is within 1.4 ulp of exp; tests/test_oracle_det.py checks the
-        // property), beyond that it saturates towards 1.0f, so everything above 10.9 is a candidate; below -80 it
-        // underflows and every class is one.
-        float thr = -__builtin_huge_valf();
-        if (!FULL) {
-            float m = -__builtin_huge_valf();
-            for (int q = 0; q < ncq; ++q) {
-                const float4 v = *(const float4*)(t + 4 * q);
-                const float sc[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (4 * q + j < a.nc) m = fmaxf(m, sc[j]);
-            }
-            thr = m > 11.0f ? 10.9f : (m < -80.0f ? -__builtin_huge_valf() : m - 0.01f);
-        }
-        for (int q = 0; q < ncq; ++q) {
-            float4 v = *(const float4*)(t + 4 * q);
-            float sc[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = 4 * q + j;
-                if (c < a.nc && (FULL || sc[j] >= thr)) {
-                    sc[j] = det_sigmoid(sc[j]);
-                    if (sc[j] > best) { best = sc[j]; bi = c; }
-                }
-            }
-            if (FULL) *(float4*)(t + 4 * q) = make_float4(sc[0], sc[1], sc[2], sc[3]);
-        }
-        a.best[row] = make_float2(best, (float)bi);
-    }
-    if (FULL) {
-        __syncthreads();
-        for (int r = rgrp; r < n_here; r += DEC_T / 16)
-            for (int c = sub; c < a.nc; c += 16) out0[(size_t)r * no + 4 + c] = tile[r * pw + c];
-    }
-    if (nk == 0) return;
-    // ---- keypoints
-    __syncthreads();
-    for (int r = rgrp; r < n_here; r += DEC_T / 16)
-        for (int q = sub; q < nkq; q += 16)
-            *(float4*)(tile + r * pw + 4 * q) = *(const float4*)(src + (size_t)r * lv.cs + lv.kpt_off + 4 * q);
-    __syncthreads();
-    if (live) {
-        float* t = tile + tid * pw;
-        for (int k = 0; k < a.nkpt; ++k) {
-            float* kp = t + k * a.kdim;
-            kp[0] = (kp[0] * 2.0f + (ax - 0.5f)) * st;
-            kp[1] = (kp[1] * 2.0f + (ay - 0.5f)) * st;
-            if (a.kdim == 3) kp[2] = det_sigmoid(kp[2]);
-        }
-    }
-    __syncthreads();
-    for (int r = rgrp; r < n_here; r += DEC_T / 16)
-        for (int c = sub; c < nk; c += 16) out0[(size_t)r * no + 4 + a.nc + c] = tile[r * pw + c];
-}
-
-// v3 ("quad"): FOUR lanes per anchor and no LDS.  Lane s of a quad owns DFL side s (its 16 logits are 64 contiguous bytes:
+// decoded row [4 box | nc scores | nk kpts] (anchor-major) plus (best score, best class).  FULL = also store the nc
+// sigmoid scores (only the raw-head parity entry point needs them: NMS reads box, keypoints and `best` only), which cuts
+// the kernel's HBM writes from 86 to 6 floats per anchor for an 80-class detector.
+// FOUR lanes per anchor and no LDS.  Lane s of a quad owns DFL side s (its 16 logits are 64 contiguous bytes:
 // four 16-byte loads), a quarter of the class logits and a quarter of the keypoint values; the four distances, the class
-// maximum and the (score, first argmax) pair are combined with wave shuffles.  The LDS kernels above stage 336 bytes per
-// anchor and so run at 1.5 waves per SIMD; this one is bound by its loads.  Per-element arithmetic and every summation
-// order are unchanged (a DFL side is still evaluated sequentially by one lane): same bits.
+// maximum and the (score, first argmax) pair are combined with wave shuffles.  (Round 1's LDS-staged one-lane-per-anchor
+// kernels staged 336 bytes per anchor and so ran at 1.5 waves per SIMD: 0.78 vs 0.36 ms per 256 frames; removed.)  A DFL
+// side is evaluated sequentially by one lane in the canonical operation order.
 template <bool FULL>
 __global__ __launch_bounds__(256) void decode_kernel_quad(DecodeArgs a) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -332,7 +84,13 @@ __global__ __launch_bounds__(256) void decode_kernel_quad(DecodeArgs a) {
         const bool vec = (a.nc & 3) == 0 && (lv.cls_off & 3) == 0;
         const int ncq = a.nc >> 2;
         float thr = -__builtin_huge_valf();
-        if (!FULL) {            // see decode_kernel_v2: only logits within a hair of the maximum can hold the best score
+        // NMS only needs max_c sigmoid(logit_c) and its FIRST argmax.  sigmoid is monotone, so only classes whose logit is
+        // within a hair of the largest one can hold or tie the maximum: evaluate the (35-instruction, bit-exact) sigmoid for
+        // those alone -- 1-2 classes instead of 80.  The window is exact, not heuristic: up to 11 the fp32 sigmoid still
+        // separates logits 0.01 apart by >= 2.8 ulp (det_expf is within 1.4 ulp of exp; tests/test_oracle_det.py checks the
+        // property), beyond that it saturates towards 1.0f, so everything above 10.9 is a candidate; below -80 it
+        // underflows and every class is one.
+        if (!FULL) {
             float m = -__builtin_huge_valf();
             if (vec) {
                 for (int q = s; q < ncq; q += 4) {
@@ -397,49 +155,13 @@ __global__ __launch_bounds__(256) void decode_kernel_quad(DecodeArgs a) {
     }
 }
 
-const char* launch_decode(const DecodeArgs& a0, bool full, hipStream_t st) {
-    DecodeArgs a = a0;
-    const int nk = a.nkpt * a.kdim;
-    int t = 0;
-    for (int l = 0; l < a.n_levels; ++l) { a.tile0[l] = t; t += (a.lv[l].H * a.lv[l].W + DEC_T - 1) / DEC_T; }
-    a.tiles_per_image = t;
-    const dim3 grid((unsigned)(a.B * t));
-    {   // quad kernel: needs 16-byte aligned box logits only
-        static const bool use_quad = []() { const char* e = getenv("MI355_DECODE_QUAD"); return e ? atoi(e) != 0 : true; }();
-        bool ok = use_quad;
-        for (int l = 0; l < a.n_levels; ++l) ok = ok && (a.lv[l].cs & 3) == 0 && (a.lv[l].box_off & 3) == 0;
-        if (ok) {
-            const long lanes = (long)a.B * a.A * 4;
-            const dim3 g((unsigned)((lanes + 255) / 256));
-            if (full) hipLaunchKernelGGL(decode_kernel_quad<true>, g, dim3(256), 0, st, a);
-            else      hipLaunchKernelGGL(decode_kernel_quad<false>, g, dim3(256), 0, st, a);
-            hipError_t e3 = hipGetLastError();
-            return e3 == hipSuccess ? nullptr : hipGetErrorString(e3);
-        }
-    }
-    bool aligned = ((4 + a.nc + nk) & 3) == 0;
+const char* launch_decode(const DecodeArgs& a, bool full, hipStream_t st) {
     for (int l = 0; l < a.n_levels; ++l)
-        aligned = aligned && (a.lv[l].cs & 3) == 0 && (a.lv[l].box_off & 3) == 0 && (a.lv[l].cls_off & 3) == 0 && (a.lv[l].kpt_off & 3) == 0;
-    if (aligned) {
-        int ps = 16;                                              // float4 slots per row: max over the three phases, made odd
-        if ((a.nc + 3) / 4 > ps) ps = (a.nc + 3) / 4;
-        if ((nk + 3) / 4 > ps) ps = (nk + 3) / 4;
-        ps |= 1;
-        const size_t lds2 = (size_t)DEC_T * ps * 16;
-        if (lds2 <= 64 * 1024) {
-            if (full) hipLaunchKernelGGL(decode_kernel_v2<true>, grid, dim3(DEC_T), lds2, st, a, ps);
-            else      hipLaunchKernelGGL(decode_kernel_v2<false>, grid, dim3(DEC_T), lds2, st, a, ps);
-            hipError_t e2 = hipGetLastError();
-            return e2 == hipSuccess ? nullptr : hipGetErrorString(e2);
-        }
-    }
-    int pw = 64;
-    if (a.nc > pw) pw = a.nc;
-    if (nk > pw) pw = nk;
-    pw |= 1;
-    const size_t lds = (size_t)DEC_T * pw * sizeof(float);
-    if (full) hipLaunchKernelGGL(decode_kernel<true>, grid, dim3(DEC_T), lds, st, a, pw);
-    else      hipLaunchKernelGGL(decode_kernel<false>, grid, dim3(DEC_T), lds, st, a, pw);
+        if ((a.lv[l].cs & 3) || (a.lv[l].box_off & 3)) return "decode: box logits must be 16-byte aligned";
+    const long lanes = (long)a.B * a.A * 4;
+    const dim3 g((unsigned)((lanes + 255) / 256));
+    if (full) hipLaunchKernelGGL(decode_kernel_quad<true>, g, dim3(256), 0, st, a);
+    else      hipLaunchKernelGGL(decode_kernel_quad<false>, g, dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

@@ -3,8 +3,8 @@ import sys
 
 import pytest
 
-os.environ.setdefault("MI355_CONV_V2", "1")     # tests also cover the opt-in loader-wave conv kernel (read once per process)
-os.environ.setdefault("MI355_CONV_V5", "1")     # ... and the opt-in persistent/prefetched 3x3 kernel
+
+
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
