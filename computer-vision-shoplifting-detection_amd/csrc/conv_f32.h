@@ -109,11 +109,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
         const int lx = p - ly * a.TW;
         xoff[pt] = ((ly * STRIDE) * a.TWin + lx * STRIDE) * a.ldp + (lane >> 4) * 4;
     }
-    f32x4 acc[CT][PT];
+    // canonical accumulation: `acc` is the fma chain of ONE 16-channel block (all taps), started from +0;
+    // `tot` is the running sum of the block partials in block order
+    f32x4 acc[CT][PT], tot[CT][PT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int pt = 0; pt < PT; ++pt) tot[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const float* srcb = a.src + (size_t)b * a.Hin * a.Win * a.src_cs;
     // cout tiles beyond the last one re-read the last tile's weights (their outputs are discarded by the epilogue):
@@ -166,65 +168,105 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
         const int rem = a.Cin - c0;
         const int nkk = ((rem < a.ck ? rem : a.ck) + 15) >> 4;
         const int cib0 = c0 >> 4;
-        // canonical accumulation order of one output: 16-channel block (outer), tap, MFMA step s, k-group g.
-        // (block, tap) is flattened into one runtime loop of pipeline steps; all offsets advance as wave-uniform
-        // scalars.  Weight fragments come from L2 with 1-2k cycles of latency under load, so they are prefetched WD
-        // steps ahead through a ring of WD register sets; pixel fragments (LDS, ~100 cycles) one step ahead through two
-        // sets.  Both cursors CLAMP at the last step instead of guarding the loads: every load is unconditional, which
-        // is what lets hipcc keep counted s_waitcnt vmcnt(N) / lgkmcnt(N) instead of draining the queues.
-        constexpr int WD = (CT <= 2) ? 4 : 2;
-        const int n_it = nkk * TAPS;
+        // K loop over the chunk's 16-channel blocks.  Canonical order of one output: per block ONE fma chain
+        // over (tap kh-major, MFMA step s, k-group g) started from +0 -- the block's first MFMA takes the constant 0 as its
+        // C operand --, then the block partial is added to the running total; blocks in ascending order.
+        // The taps are unrolled at compile time (their LDS / weight offsets are loop-invariant), the only running scalars
+        // are the current and the next block base, and nothing in the loop branches: the accumulators stay in place and
+        // every load is unconditional, so hipcc keeps counted s_waitcnt vmcnt(N) / lgkmcnt(N).  Fragments travel through
+        // register rings: weights (L2, 500+ cycles) RW - 1 steps ahead, pixels (LDS) one step ahead; loads past the
+        // chunk's last block re-read it.
+        constexpr int RX = TAPS > 1 ? 2 : 3;                       // 3x3: two pixel sets; the odd tap count is squared up by one
+                                                                   // register copy per block (below)
+        constexpr int RW = (TAPS > 1 && PT * CT <= 2) ? 9 : 3;     // small wave tiles: a step is only 128-256 MFMA cycles
+        static_assert(TAPS == 1 || TAPS % RW == 0, "weight ring slots must line up across blocks");
         const int wstep = a.cib * 256;
-        int w_it = 0, w_kw = 0, w_kh = 0, w_kk = 0, w_off = cib0 * 256;     // weight cursor: (tap*cib + cib0 + kk)*256 floats
-        int x_it = 0, x_kw = 0, x_kh = 0, x_kk = 0, x_off = 0;              // pixel cursor: (kh*TWin + kw)*ldp + kk*16 floats
-        f32x4 wf[WD][CT], xf[2][PT];
-        auto load_w = [&](f32x4* w) {
+        const int klast = nkk - 1;
+        f32x4 wf[RW][CT], xf[RX][PT];
+        auto opaque = [](int v) { asm volatile("" : "+s"(v)); return v; };     // keeps a scalar sum out of LICM's hands
+        auto load_w = [&](f32x4* w, int off) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(wbase[ct] + w_off);
-            if (w_it + 1 < n_it) {
-                ++w_it; ++w_kw; w_off += wstep;
-                if (w_kw == KS) {
-                    w_kw = 0; ++w_kh;
-                    if (w_kh == KS) { w_kh = 0; ++w_kk; w_off = (cib0 + w_kk) * 256; }
-                }
-            }
+            for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(wbase[ct] + off);
         };
-        auto load_x = [&](f32x4* x) {
+        auto load_x = [&](f32x4* x, int off) {
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) x[pt] = *(const f32x4*)__builtin_assume_aligned(lds + xoff[pt] + x_off, 16);
-            if (x_it + 1 < n_it) {
-                ++x_it; ++x_kw; x_off += a.ldp;
-                if (x_kw == KS) {
-                    x_kw = 0; ++x_kh; x_off += (a.TWin - KS) * a.ldp;
-                    if (x_kh == KS) { x_kh = 0; ++x_kk; x_off = x_kk * 16; }
-                }
-            }
+            for (int pt = 0; pt < PT; ++pt) x[pt] = *(const f32x4*)__builtin_assume_aligned(lds + xoff[pt] + off, 16);
         };
-        auto mma = [&](const f32x4* w, const f32x4* x) {
+        auto mma = [&](const f32x4* w, const f32x4* x, bool first) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt)
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][s], x[pt][s], acc[ct][pt], 0, 0, 0);
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][s], x[pt][s],
+                                                                           (first && s == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[ct][pt], 0, 0, 0);
         };
+        auto bank = [&]() {                                      // end of a block: its partial joins the total
 #pragma unroll
-        for (int j = 0; j < WD - 1; ++j) load_w(wf[j]);        // steps 0 .. WD-2
-        load_x(xf[0]);                                          // step 0
-        for (int it = 0; it < n_it; it += 4) {
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                load_w(wf[(j + WD - 1) % WD]);                  // step it+j+WD-1 (clamped)
-                load_x(xf[(j + 1) & 1]);                        // step it+j+1    (clamped)
-                __builtin_amdgcn_sched_barrier(0);
-                if (it + j < n_it) mma(wf[j % WD], xf[j & 1]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int pt = 0; pt < PT; ++pt) tot[ct][pt] += acc[ct][pt];
+        };
+        if constexpr (TAPS > 1) {
+            int xt[TAPS], wt[TAPS];
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) { xt[t] = ((t / KS) * a.TWin + (t % KS)) * a.ldp; wt[t] = t * wstep; }
+            // prologue: weight steps 0 .. RW-2 and pixel step 0 of the first block (a block has TAPS >= RW - 1 steps)
+#pragma unroll
+            for (int t = 0; t < RW - 1; ++t) load_w(wf[t], cib0 * 256 + wt[t]);
+            load_x(xf[0], xt[0]);
+            for (int kb = 0; kb < nkk; ++kb) {
+                const int kn = kb < klast ? kb + 1 : klast;
+                const int wk = opaque((cib0 + kb) * 256), wkn = opaque((cib0 + kn) * 256);
+                const int xk = opaque(kb * 16), xkn = opaque(kn * 16);
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    constexpr int AW = RW - 1;
+                    load_w(wf[(t + AW) % RW], opaque(((t + AW) >= TAPS ? wkn : wk) + wt[(t + AW) % TAPS]));
+                    load_x(xf[(t + 1) % RX], opaque(((t + 1) >= TAPS ? xkn : xk) + xt[(t + 1) % TAPS]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(wf[t % RW], xf[t % RX], t == 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                bank();
+                if constexpr (TAPS % RX != 0) {                  // the next block's tap 0 landed in slot TAPS % RX: move it to slot 0
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) xf[0][pt] = xf[TAPS % RX][pt];
+                }
+            }
+        } else {
+            // pointwise: a step is a block; RX blocks per trip so that the ring slots are compile-time
+            auto koff = [&](int kb) { return kb < klast ? kb : klast; };
+            load_w(wf[0], (cib0 + koff(0)) * 256);
+            load_w(wf[1], (cib0 + koff(1)) * 256);
+            load_x(xf[0], 0);
+            int kb0 = 0;
+            for (; kb0 + RX <= nkk; kb0 += RX) {              // whole trips: no guard, no branch inside
+#pragma unroll
+                for (int t = 0; t < RX; ++t) {
+                    load_w(wf[(t + 2) % RW], opaque((cib0 + koff(kb0 + t + 2)) * 256));
+                    load_x(xf[(t + 1) % RX], opaque(koff(kb0 + t + 1) * 16));
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(wf[t % RW], xf[t % RX], true);
+                    bank();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (kb0 < nkk) {                                  // ragged tail trip
+#pragma unroll
+                for (int t = 0; t < RX; ++t) {
+                    load_w(wf[(t + 2) % RW], opaque((cib0 + koff(kb0 + t + 2)) * 256));
+                    load_x(xf[(t + 1) % RX], opaque(koff(kb0 + t + 1) * 16));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kb0 + t < nkk) { mma(wf[t % RW], xf[t % RX], true); bank(); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
 
-    conv_epilogue<STRIDE, PT, CT, WP>(a, acc, bias4, lane, wp, ct0, b, oy0, ox0, npix);
+    conv_epilogue<STRIDE, PT, CT, WP>(a, tot, bias4, lane, wp, ct0, b, oy0, ox0, npix);
 }
 
 // ---------------------------------------------------------------------------------------------- v3 (1x1 only)
@@ -232,7 +274,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
 // fragments straight from global memory into the MFMA B-operand layout (lane (p, g) reads the 16 bytes of channels
 // 4g..4g+3 of pixel p: 64 contiguous bytes per pixel per 16-channel block), with a 4-deep register prefetch ring for
 // pixels (HBM latency) and weights (L2 latency).  No LDS, no barriers: waves drift apart and overlap each other's
-// epilogues.  Same canonical accumulation order as v1 (16-channel block outer, step s, k-group g).
+// epilogues.  Same canonical accumulation order as v1 (per 16-channel block a chain from +0; partials summed in block order).
 template <int PT, int CT>
 __global__ __launch_bounds__(256) void conv1x1_stream_f32(ConvKArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -253,7 +295,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_f32(ConvKArgs a) {
         const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
         wbase[ct] = a.wpk + (size_t)ctile * a.cib * 256 + lane * 4;
     }
-    f32x4 acc[CT][PT];
+    f32x4 acc[CT][PT];                                               // running sum of the 16-channel block partials
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -282,14 +324,16 @@ __global__ __launch_bounds__(256) void conv1x1_stream_f32(ConvKArgs a) {
         }
         if (l_it + 1 < n_it) ++l_it;                                 // clamp instead of guarding the loads
     };
-    auto mma = [&](const f32x4* w, const f32x4* x) {
+    auto mma = [&](const f32x4* w, const f32x4* x) {              // one 16-channel block: chain from +0, partial added to the sum
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+            for (int pt = 0; pt < PT; ++pt) {
+                f32x4 p = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][0], x[pt][0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt)
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][s], x[pt][s], acc[ct][pt], 0, 0, 0);
+                for (int s = 1; s < 4; ++s) p = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][s], x[pt][s], p, 0, 0, 0);
+                acc[ct][pt] += p;
+            }
     };
 #pragma unroll
     for (int j = 0; j < D - 1; ++j) load(wf[j], xf[j]);
@@ -337,7 +381,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_f32(ConvKArgs a) {
 // already in flight into registers, and the stores of the previous tile drain behind them.  vmcnt retires in order, so
 // the order of issue is what makes this work: the chunk's weight fragments (all of them: a 1x1 chunk has at most 4 k-blocks)
 // are requested BEFORE the prefetch, hence waiting for them never waits for the prefetch.
-// Same canonical accumulation order as v1 (16-channel block outer, step s, k-group g): same bits.
+// Same canonical accumulation order as v1 (per 16-channel block a chain over step s, k-group g; partials summed in block order): same bits.
 template <int PT, int CT, int WP, bool SINGLE, int NKK>   // SINGLE: Cin fits one chunk -> every item ends a tile; NKK: k-blocks per chunk
 __global__ __launch_bounds__(256) void conv1x1_pipe_f32(ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -438,14 +482,20 @@ __global__ __launch_bounds__(256) void conv1x1_pipe_f32(ConvKArgs a) {
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) xf[(kk + 1) & 1][pt] = *(const f32x4*)__builtin_assume_aligned(lds + xoff[pt] + kn, 16);
             __builtin_amdgcn_sched_barrier(0);
-            if (kk < nkk) {
+            if (kk < nkk) {                                    // one 16-channel block: chain from +0, partial added to the sum
+                f32x4 p[CT][PT];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                         for (int pt = 0; pt < PT; ++pt)
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kk][ct][s], xf[kk & 1][pt][s], acc[ct][pt], 0, 0, 0);
+                            p[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kk][ct][s], xf[kk & 1][pt][s],
+                                                                             s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : p[ct][pt], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) acc[ct][pt] += p[ct][pt];
             }
             __builtin_amdgcn_sched_barrier(0);
         }

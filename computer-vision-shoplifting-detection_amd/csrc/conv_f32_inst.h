@@ -7,13 +7,15 @@ namespace mi355 {
 
 typedef void (*KernelFn)(ConvKArgs);
 
-// conv_igemm_f32<KS, STRIDE, PT = (CT == 5 ? 3 : 4), CT, WP>: CT in 1..5, WP in {1, 2, 4}
-KernelFn pick_f32_k3s1(int CT, int WP);       // conv_f32_k3s1.hip
-KernelFn pick_f32_k3s2(int CT, int WP);       // conv_f32_k3s2.hip
-KernelFn pick_f32_k1(int CT, int WP);         // conv_f32_k1.hip
-// conv1x1_stream_f32<PT, CT>: CT in {1, 2, 4}, PT in {2, 4}
+// conv_igemm_f32<KS, STRIDE, PT, CT, WP>: PT 0 = the default wave tile (4 pixel tiles, 3 with CT 5), CT in 1..5;
+// PT 1 / 2 = small wave tiles for latency-bound launches, CT in {1, 2}; WP in {1, 2, 4}
+KernelFn pick_f32_k3s1(int CT, int WP, int PT);       // conv_f32_k3s1.hip
+KernelFn pick_f32_k3s2(int CT, int WP, int PT);       // conv_f32_k3s2.hip
+KernelFn pick_f32_k1(int CT, int WP, int PT);         // conv_f32_k1.hip
+// conv1x1_stream_f32<PT, CT>: CT in {1, 2, 4}, PT in {1, 2, 4}
 KernelFn pick_f32_stream(int CT, int PT);     // conv_f32_k1.hip
-// conv1x1_pipe_f32<4, CT, WP, SINGLE, NKK>: CT in {1, 2, 4} (NKK 8: CT <= 2), WP in {1, 2, 4}; NKK = 8 when ck > 64
-KernelFn pick_f32_pipe(int CT, int WP, bool single, int ck);   // conv_f32_pipe.hip
+// conv1x1_pipe_f32<PT, CT, WP, SINGLE, NKK>: PT 0 / 4 = 4 pixel tiles per wave (NKK = 8 when ck > 64, then CT <= 2), PT 1 / 2 =
+// small pixel tiles for latency-bound launches (ck <= 64); CT in {1, 2, 4}, WP in {1, 2, 4}
+KernelFn pick_f32_pipe(int CT, int WP, bool single, int ck, int PT);   // conv_f32_pipe.hip
 
 }  // namespace mi355

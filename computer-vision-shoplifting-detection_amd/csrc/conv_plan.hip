@@ -32,10 +32,10 @@ namespace {
 
 struct Plan { int CT, WP, TW, TH, ck; size_t lds; double cost; int version; int buf_floats; int PT; };   // PT 0 = default (4, or 3 with CT 5)
 
-KernelFn pick_kernel(int ks, int stride, int CT, int WP) {
-    if (ks == 1 && stride == 1) return pick_f32_k1(CT, WP);
-    if (ks == 3 && stride == 1) return pick_f32_k3s1(CT, WP);
-    if (ks == 3 && stride == 2) return pick_f32_k3s2(CT, WP);
+KernelFn pick_kernel(int ks, int stride, int CT, int WP, int PT) {
+    if (ks == 1 && stride == 1) return pick_f32_k1(CT, WP, PT);
+    if (ks == 3 && stride == 1) return pick_f32_k3s1(CT, WP, PT);
+    if (ks == 3 && stride == 2) return pick_f32_k3s2(CT, WP, PT);
     return nullptr;
 }
 
@@ -48,18 +48,46 @@ constexpr size_t LDS_SOFT = 40 * 1024, LDS_HARD = 64 * 1024;
 
 // Candidate launch plans for one conv: for every wave arrangement (CT, WC) the best output tile, with every
 // feasible staged-channel count.  Sorted by a static cost model; the engine may time the first few (autotune).
-std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, int stride, bool have_zero_page, bool half) {
+// Launch-time model used to rank candidates, in matrix-pipe cycles: a launch takes at least the padded MFMA work spread over
+// the chip's 1024 SIMDs (throughput) and at least one wave's own serial MFMA chain plus a fixed start-up (staging latency,
+// epilogue).  Large batches are throughput-bound and rank by padding waste as before; a batch-1 map has so few pixel tiles
+// that the serial chain of a 64-pixel wave tile dominates, and plans with 1-2 pixel tiles per wave (more, shorter waves)
+// move to the front.
+constexpr double SIMDS = 1024.0, MFMA_CYCLES = 32.0, WAVE_STARTUP_CYCLES = 6000.0;
+
+struct Shape { int H, W, n_ctiles, cin16, ks, stride; };
+
+double latency_factor(const Shape& sh, long blocks, int PT, int CT) {
+    const double per_wave = (double)PT * CT * sh.ks * sh.ks * (sh.cin16 / 4) * MFMA_CYCLES;       // one wave's MFMA chain
+    const double thru = (double)blocks * 4.0 * per_wave / SIMDS;
+    return std::max(1.0, (per_wave + WAVE_STARTUP_CYCLES) / std::max(thru, 1.0));
+}
+
+// Candidate launch plans for one conv: for every wave arrangement (CT, WC) the best output tile, with every
+// feasible staged-channel count.  Sorted by a static cost model; the engine may time the first few (autotune).
+std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int cin, int ks, int stride, bool have_zero_page, bool half) {
     static const int max_ct = env_int("MI355_MAX_CT", 5);          // tuning knobs (experiments only)
     static const int min_wc = env_int("MI355_MIN_WC", 1);
+    static const int small_pt = env_int("MI355_SMALL_PT", 1);      // 0: never offer the 1- / 2-pixel-tile wave shapes
     std::vector<Plan> out;
     const int cin16 = round_up(cin, 16);
-    // fp16 only: wave tiles of 8 pixel tiles (128 pixels x CT*16 couts) halve the weight bytes fetched per MFMA -- the f16
-    // MFMA retires a 1-KiB fragment pair in 16 cycles, so these kernels are bound by L1/L2 fragment traffic, not by the pipe
-    for (int PTsel = 0; PTsel <= (half ? 8 : 0); PTsel += 8)
+    const Shape sh{H, W, n_ctiles, cin16, ks, stride};
+    // Is the default wave tile (4 pixel tiles) latency-bound on this shape?  Only then are the small wave tiles offered: at
+    // large batches they would only crowd the autotuner's candidate list.
+    const bool latency_bound = !half && small_pt &&
+                               latency_factor(sh, ((long)W * H + 63) / 64 * images * ((n_ctiles + 3) / 4), 4, 1) > 1.0;
+    // Pixel tiles per wave.  fp16: wave tiles of 8 pixel tiles (128 pixels x CT*16 couts) halve the weight bytes fetched per
+    // MFMA -- the f16 MFMA retires a 1-KiB fragment pair in 16 cycles, so those kernels are bound by L1/L2 fragment traffic.
+    // fp32: 0 = the default (4, or 3 with CT 5); 2 and 1 for latency-bound launches.
+    std::vector<int> pt_sel = {0};
+    if (half) pt_sel.push_back(8);
+    else if (latency_bound) { pt_sel.push_back(2); pt_sel.push_back(1); }
+    for (int PTsel : pt_sel)
     for (int WC = 1; WC <= 4; WC *= 2)
         for (int CT = 1; CT <= 5; ++CT) {
             if (CT > max_ct || WC < min_wc) continue;
             if (PTsel == 8 && CT > 4) continue;
+            if (!half && PTsel != 0 && CT > 2) continue;               // small wave tiles exist for CT 1 and 2
             const int WP = 4 / WC, PT = PTsel ? PTsel : (CT == 5 ? 3 : 4), P = WP * PT * 16;
             const int cover = CT * WC, nblk = (n_ctiles + cover - 1) / cover;
             if (cover >= 2 * n_ctiles && cover > CT) continue;          // more than half of the cout tiles would be padding
@@ -81,6 +109,7 @@ std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, i
                     const int stages = (cin16 + ck - 1) / ck;
                     double cost = infl * (1.0 + 0.03 * halo * nblk) * (1.0 + 0.04 * (stages - 1)) * (1.0 + 0.04 * (CT - 1))
                                   + (lds > LDS_SOFT ? 0.15 : 0.0);
+                    if (latency_bound) cost *= latency_factor(sh, tiles * images * nblk, PT, CT);
                     if (cost < best.cost) best = Plan{CT, WP, TW, TH, ck, lds, cost, 1, 0, PTsel};
                 }
                 if (best.cost < 1e30) out.push_back(best);
@@ -88,37 +117,50 @@ std::vector<Plan> enumerate_plans(int H, int W, int n_ctiles, int cin, int ks, i
         }
     if (ks == 1 && have_zero_page) {        // streaming pointwise kernel (needs the zero page as well): CT x PT register tiles
         static const int use_v3 = env_int("MI355_CONV_V3", 1);
-        const int cts[3] = {1, 2, 4}, pts[2] = {2, 4};
+        const int cts[3] = {1, 2, 4}, pts[3] = {2, 4, 1};
         for (int ci = 0; ci < 3 && use_v3; ++ci)
-            for (int pi = 0; pi < 2; ++pi) {
+            for (int pi = 0; pi < ((latency_bound && !half) ? 3 : 2); ++pi) {
                 const int CT = cts[ci], PT = pts[pi];
                 if (CT > n_ctiles && CT != 1) continue;
                 const int nblk = (n_ctiles + CT - 1) / CT;
                 Plan p3{CT, 4, PT * 64, 1, 16, 0, 0.0, 3, PT, 0};
                 p3.cost = (double)nblk * CT / n_ctiles * (1.0 + 0.05 * nblk) * 0.9;
+                if (latency_bound) p3.cost *= latency_factor(sh, ((long)W + PT * 64 - 1) / (PT * 64) * nblk, PT, CT);
                 out.push_back(p3);
             }
     }
     if (ks == 1 && have_zero_page) {   // persistent software-pipelined pointwise kernel (v4); ck in 4-byte units (fp16: 2 channels each)
         static const int use_v4 = env_int("MI355_CONV_V4", 1);
         const int wps[3] = {1, 2, 4}, cts[4] = {1, 2, 4, 3}, cks[4] = {128, 64, 32, 16};
+        for (int PT : (latency_bound && !half) ? std::vector<int>{4, 2, 1} : std::vector<int>{4})
         for (int wi = 0; wi < 3 && use_v4; ++wi)
             for (int ci = 0; ci < (half ? 4 : 3); ++ci)
                 for (int ki = 0; ki < 4; ++ki) {
-                    const int WP = wps[wi], WC = 4 / WP, CT = cts[ci], ck = cks[ki], P = WP * 64;
+                    const int WP = wps[wi], WC = 4 / WP, CT = cts[ci], ck = cks[ki], P = WP * PT * 16;
                     const int cover = CT * WC, nblk = (n_ctiles + cover - 1) / cover;
                     if (cover >= 2 * n_ctiles && cover > CT) continue;
                     if (ck > cin16 && ck != 16) continue;
                     if (P * ck / 4 > 2048) continue;                       // 8 prefetch registers (float4) per thread
-                    if (ck > 64 && CT > (half ? 3 : 2)) continue;          // a chunk's weights live in registers: 8 k-blocks x CT fragments
+                    if (ck > 64 && (CT > (half ? 3 : 2) || PT != 4)) continue;   // a chunk's weights live in registers: 8 k-blocks x CT fragments
                     const size_t lds = (size_t)P * (ck + 4) * 4;
                     const int stages = (cin16 + ck - 1) / ck;
-                    Plan p4{CT, WP, P, 1, ck, lds, 0.0, 4, 0, 0};
+                    Plan p4{CT, WP, P, 1, ck, lds, 0.0, 4, 0, PT == 4 ? 0 : PT};
                     p4.cost = (double)nblk * cover / n_ctiles * (1.0 + 0.03 * (stages - 1)) * (1.0 + 0.02 * nblk) * 0.8;
+                    if (latency_bound) p4.cost *= latency_factor(sh, ((long)W + P - 1) / P * nblk, PT, CT);
                     out.push_back(p4);
                 }
     }
     std::sort(out.begin(), out.end(), [](const Plan& a, const Plan& b) { return a.cost < b.cost; });
+    if (latency_bound) {
+        // the latency model is crude: let the timed top-N hold both families, best of each alternating
+        std::vector<Plan> big, small, merged;
+        for (const Plan& p : out) ((p.PT == 0 || p.PT >= 4) && !(p.version == 3 && p.buf_floats == 1) ? big : small).push_back(p);
+        for (size_t i = 0; i < std::max(big.size(), small.size()); ++i) {
+            if (i < small.size()) merged.push_back(small[i]);
+            if (i < big.size()) merged.push_back(big[i]);
+        }
+        out.swap(merged);
+    }
     return out;
 }
 
@@ -162,7 +204,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     KernelFn fn = half ? (p.version == 4 ? (KernelFn)pick_conv_pipe_f16(p.CT, p.WP, (c.Cin + 1) / 2 <= p.ck, p.ck > 64)
                                          : (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.version == 3 ? p.buf_floats : p.PT))
                        : (p.version == 3 ? pick_f32_stream(p.CT, p.buf_floats)
-                          : p.version == 4 ? pick_f32_pipe(p.CT, p.WP, c.Cin <= p.ck, p.ck) : pick_kernel(c.k, c.stride, p.CT, p.WP));
+                          : p.version == 4 ? pick_f32_pipe(p.CT, p.WP, c.Cin <= p.ck, p.ck, p.PT) : pick_kernel(c.k, c.stride, p.CT, p.WP, p.PT));
     if (!fn) return "conv: no kernel instance";
     a.zeros = c.zeros; a.lds_buf_floats = p.buf_floats;
     if (half && p.version == 4) a.lds_buf_floats = 0;
@@ -213,8 +255,9 @@ const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out
     if (const char* e = check_args(c)) return e;
     const int H = c.k == 1 ? 1 : c.Hout, W = c.k == 1 ? c.B * c.Hout * c.Wout : c.Wout;
     const bool half = c.dtype == 1;
-    const std::vector<Plan> plans = enumerate_plans(H, W, (c.Cout + 15) / 16, half ? (c.Cin + 1) / 2 : c.Cin, c.k, c.stride,
-                                                    c.zeros != nullptr, half);
+    // H x W = the map one block grid walks: the image for 3x3 convs (`images` of them), batch x space flattened for 1x1
+    const std::vector<Plan> plans = enumerate_plans(H, W, c.k == 1 ? 1 : c.B, (c.Cout + 15) / 16, half ? (c.Cin + 1) / 2 : c.Cin, c.k,
+                                                    c.stride, c.zeros != nullptr, half);
     if (plans.empty()) return "conv: no launch plan fits in LDS";
     for (const Plan& p : plans) {
         if (c.src2 && p.version != 4) continue;       // upsample-on-read exists in the v4 kernels only

@@ -119,7 +119,7 @@ struct mi355_yolo {
     int chunk = 64;
     // tuned launch-plan choice per (frames, H, W): candidate index per op, so a shape seen before is not re-timed
     std::vector<std::pair<std::array<int, 3>, std::vector<int>>> tuned;
-    int autotune = 24;                  // candidate launch plans timed per conv when a shape is first seen (0 = off)
+    int autotune = 32;                  // candidate launch plans timed per conv when a shape is first seen (0 = off)
     long long n_params = 0, macs640 = 0;
 
     // per-shape state

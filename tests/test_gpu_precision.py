@@ -4,11 +4,11 @@ Ultralytics CPU path", measured the only way fp32 allows it.
 Yardstick: a float64 execution of the same fused program (tools/precision.py).  Two fp32 implementations are measured
 against it on the same frames: the torch-CPU oracle (the restated Ultralytics path, oracle/yolo_oracle.py) and the GPU
 engine.  Asserted:
-  1. the engine is as close to float64 as torch is -- per channel group (box px, score, keypoint px, keypoint conf) and per
-     statistic: err_gpu <= RATIO * err_torch for mean and p99.9 (RATIO_MAX for the max).  RATIO is 2.0, not 1.0: the engine
-     accumulates each output as ONE k-ordered fma chain (what makes it bit-reproducible on a CPU) while
-     torch/oneDNN sum in SIMD-wide blocks, which is worth a factor in rounding noise that grows with the chain length
-     (measured: 1.26-1.36 on YOLOv8n / n-pose, 1.3-1.5 on YOLOv8s-pose; the ratios are printed);
+  1. the engine is AT LEAST as close to float64 as torch is -- per channel group (box px, score, keypoint px, keypoint conf)
+     and per statistic: err_gpu <= 1.0 * err_torch for mean and p99.9 (1.5 for the max, a single sample).  This holds because
+     of the engine's two-level ("blocked") accumulation: each 16-channel block is one fma chain from +0 and the block partials
+     are added in order -- measured 0.88-0.93 x torch's error on YOLOv8n / n-pose, 0.64-0.70 on YOLOv8s-pose.
+     (Round 1 summed all of K in ONE chain: bit-reproducible too, but 1.3-1.5 x torch's error, growing with K.)
   2. absolute levels: scores within 1e-3 (1.2e-4 measured); box mean error < 1e-3 px.  The MAX box error of ANY fp32
      implementation on these random-weight heads is ~1e-2 px (torch itself: 1.5e-2): the DFL expectation times stride 32
      amplifies 1e-5 relative logit noise, so "1e-3 on every coordinate" is not a property fp32 torch has either;
@@ -25,8 +25,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-RATIO = 2.0            # err(gpu vs f64) <= RATIO * err(torch vs f64) for mean and p99.9; see the module docstring for why not 1.0
-RATIO_MAX = 3.0        # ... for the max, a single-sample statistic of ~1e6 values (measured 0.9 - 1.7)
+RATIO = 1.0            # err(gpu vs f64) <= RATIO * err(torch vs f64) for mean and p99.9 (measured 0.64 - 0.93)
+RATIO_MAX = 1.5        # ... for the max, a single-sample statistic of ~1e6 values (measured 0.42 - 1.35)
 SCORE_ABS = 1e-3       # north_star's tolerance, attainable for scores (sigmoid output, no stride amplification)
 BOX_MEAN_ABS = 1e-3    # px
 MARGIN_NOISE = {"conf threshold": 5e-4, "score order": 5e-4, "iou threshold": 5e-3}
