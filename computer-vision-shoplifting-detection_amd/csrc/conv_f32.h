@@ -269,6 +269,159 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
     conv_epilogue<STRIDE, PT, CT, WP>(a, tot, bias4, lane, wp, ct0, b, oy0, ox0, npix);
 }
 
+// ---------------------------------------------------------------------------------------------- v6 (3x3, split K)
+// Latency-bound launches (batch 1: a 20x20 map is 25 pixel tiles, a 3x3 conv over 256 channels a chain of 576 MFMAs per
+// accumulator): the four waves of a block work on the SAME PT x CT tiles and split the 16-channel blocks between them
+// (wave w takes blocks w, w + 4, ... of every staged chunk), so a wave's serial MFMA chain is a quarter as long.  This is
+// bit-exact BECAUSE the canonical order is blocked: a block partial is one chain from +0 whoever computes it; the partials
+// go to LDS (1 KiB per tile and block) and are then added in ascending block order, exactly as the one-wave kernels do in
+// registers.  LDS = [halo tile of one chunk | cib x CT x PT partial tiles].
+template <int KS, int STRIDE, int PT, int CT>
+__global__ __launch_bounds__(256) void conv_splitk_f32(ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TAPS = KS * KS;
+    static_assert(TAPS == 9, "split-K kernel is written for 3x3 convs");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform by construction: lets the K offsets live in SGPRs
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
+    const int ct0 = blockIdx.y * CT;
+    const int npix = a.TW * a.TH;
+    float* part = lds + a.lds_buf_floats;                       // [cib][CT][PT][64 lanes][4]
+    int xoff[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        int p = pt * 16 + (lane & 15);
+        p = p < npix ? p : 0;
+        const int ly = (int)(((float)p + 0.5f) * a.inv_TW);
+        const int lx = p - ly * a.TW;
+        xoff[pt] = ((ly * STRIDE) * a.TWin + lx * STRIDE) * a.ldp + (lane >> 4) * 4;
+    }
+    const float* srcb = a.src + (size_t)b * a.Hin * a.Win * a.src_cs;
+    const float* wbase[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        wbase[ct] = a.wpk + (size_t)ctile * TAPS * a.cib * 256 + lane * 4;
+    }
+    const int ck4m = (a.ck >> 2) - 1;
+    const int total_f4 = a.npix_in << a.ck4_shift;
+    const int wstep = a.cib * 256;
+    int xt[TAPS], wt[TAPS];
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) { xt[k] = ((k / KS) * a.TWin + (k % KS)) * a.ldp; wt[k] = k * wstep; }
+
+    for (int c0 = 0; c0 < a.Cin; c0 += a.ck) {
+        if (c0) __syncthreads();
+        for (int base = 0; base < total_f4; base += 8 * 256) {  // stage the halo tile of this chunk (as in conv_igemm_f32)
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int pix = idx >> a.ck4_shift, q = idx & ck4m;
+                const int iy = (int)(((float)pix + 0.5f) * a.inv_TWin);
+                const int ix = pix - iy * a.TWin;
+                const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + 4 * q;
+                const bool inb = idx < total_f4 && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && c < a.cin4;
+                const float* g = inb ? srcb + ((size_t)gy * a.Win + gx) * a.src_cs + c : a.zeros;
+                v[u] = *(const f32x4*)g;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                if (idx < total_f4) {
+                    const int pix = idx >> a.ck4_shift, q = idx & ck4m;
+                    *(f32x4*)(lds + pix * a.ldp + 4 * q) = v[u];
+                }
+            }
+        }
+        __syncthreads();
+        const int rem = a.Cin - c0;
+        const int nkk = ((rem < a.ck ? rem : a.ck) + 15) >> 4;
+        const int cib0 = c0 >> 4;
+        const int n_my = wave < nkk ? (nkk - wave + 3) >> 2 : 0;   // this wave's blocks: wave, wave + 4, ...
+        if (n_my > 0) {
+            constexpr int RW = TAPS, AW = RW - 1;                   // a whole block of weight fragments in flight
+            f32x4 wf[RW][CT], xf[2][PT], acc[CT][PT];
+            auto opaque = [](int v) { asm volatile("" : "+s"(v)); return v; };
+            auto load_w = [&](f32x4* w, int off) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(wbase[ct] + off);
+            };
+            auto load_x = [&](f32x4* x, int off) {
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) x[pt] = *(const f32x4*)__builtin_assume_aligned(lds + xoff[pt] + off, 16);
+            };
+#pragma unroll
+            for (int k = 0; k < AW; ++k) load_w(wf[k], (cib0 + wave) * 256 + wt[k]);
+            load_x(xf[0], wave * 16 + xt[0]);
+            for (int i = 0; i < n_my; ++i) {
+                const int kb = wave + 4 * i, kn = i + 1 < n_my ? kb + 4 : kb;
+                const int wk = opaque((cib0 + kb) * 256), wkn = opaque((cib0 + kn) * 256);
+                const int xk = opaque(kb * 16), xkn = opaque(kn * 16);
+#pragma unroll
+                for (int k = 0; k < TAPS; ++k) {
+                    load_w(wf[(k + AW) % RW], opaque(((k + AW) >= TAPS ? wkn : wk) + wt[(k + AW) % TAPS]));
+                    load_x(xf[(k + 1) & 1], opaque(((k + 1) >= TAPS ? xkn : xk) + xt[(k + 1) % TAPS]));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                            for (int pt = 0; pt < PT; ++pt)
+                                acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[k % RW][ct][s], xf[k & 1][pt][s],
+                                                                                   (k == 0 && s == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[ct][pt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                float* pb = part + (size_t)(cib0 + kb) * (CT * PT * 256) + lane * 4;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) *(f32x4*)(pb + (ct * PT + pt) * 256) = acc[ct][pt];
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) xf[0][pt] = xf[1][pt];   // TAPS is odd: next block's tap 0 landed in slot 1
+            }
+        }
+    }
+    __syncthreads();
+    // ---- finalize: tile i = ct * PT + pt goes to wave i % 4; partials added in ascending block order, then the epilogue
+#pragma unroll
+    for (int i = 0; i < CT * PT; ++i) {
+        if ((i & 3) != wave) continue;
+        const int ct = i / PT, pt = i % PT;
+        f32x4 tot = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* pb = part + i * 256 + lane * 4;
+        for (int cb = 0; cb < a.cib; ++cb) tot += *(const f32x4*)(pb + (size_t)cb * (CT * PT * 256));
+        const int ctile = ct0 + ct;
+        const int c = ctile * 16 + (lane >> 4) * 4;
+        const int p = pt * 16 + (lane & 15);
+        const int pp = p < npix ? p : 0;
+        const int ly = (int)(((float)pp + 0.5f) * a.inv_TW);
+        const int lx = pp - ly * a.TW;
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        if (!((p < npix) && (oy < a.Hout) && (ox < a.Wout)) || ctile >= a.n_ctiles || c >= a.Cout) continue;
+        f32x4 v = tot + *(const f32x4*)(a.bias + ctile * 16 + (lane >> 4) * 4);
+        if (a.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+        const size_t po = ((size_t)b * a.Hout + oy) * a.Wout + ox;
+        float* d = a.dst + po * a.dst_cs + c;
+        if (c + 3 < a.Cout) {
+            if (a.res) v += *(const f32x4*)(a.res + po * a.res_cs + c);
+            *(f32x4*)d = v;
+        } else {
+            for (int j = 0; j < 4 && c + j < a.Cout; ++j) {
+                float r = v[j];
+                if (a.res) r += a.res[po * a.res_cs + c + j];
+                d[j] = r;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- v3 (1x1 only)
 // Pointwise convs have no tap reuse, so staging pixels through LDS buys nothing: here every wave streams its pixel
 // fragments straight from global memory into the MFMA B-operand layout (lane (p, g) reads the 16 bytes of channels

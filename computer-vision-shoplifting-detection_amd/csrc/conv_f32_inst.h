@@ -18,4 +18,7 @@ KernelFn pick_f32_stream(int CT, int PT);     // conv_f32_k1.hip
 // small pixel tiles for latency-bound launches (ck <= 64); CT in {1, 2, 4}, WP in {1, 2, 4}
 KernelFn pick_f32_pipe(int CT, int WP, bool single, int ck, int PT);   // conv_f32_pipe.hip
 
+// conv_splitk_f32<3, STRIDE, PT, CT>: PT, CT in {1, 2}
+KernelFn pick_f32_splitk(int stride, int CT, int PT);   // conv_f32_splitk.hip
+
 }  // namespace mi355

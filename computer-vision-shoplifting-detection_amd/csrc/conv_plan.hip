@@ -57,8 +57,9 @@ constexpr double SIMDS = 1024.0, MFMA_CYCLES = 32.0, WAVE_STARTUP_CYCLES = 6000.
 
 struct Shape { int H, W, n_ctiles, cin16, ks, stride; };
 
-double latency_factor(const Shape& sh, long blocks, int PT, int CT) {
-    const double per_wave = (double)PT * CT * sh.ks * sh.ks * (sh.cin16 / 4) * MFMA_CYCLES;       // one wave's MFMA chain
+double latency_factor(const Shape& sh, long blocks, int PT, int CT, int split = 1) {
+    const int kblocks = (sh.cin16 / 16 + split - 1) / split;                                          // 16-channel blocks per wave
+    const double per_wave = (double)PT * CT * sh.ks * sh.ks * kblocks * 4 * MFMA_CYCLES;              // one wave's MFMA chain
     const double thru = (double)blocks * 4.0 * per_wave / SIMDS;
     return std::max(1.0, (per_wave + WAVE_STARTUP_CYCLES) / std::max(thru, 1.0));
 }
@@ -115,6 +116,36 @@ std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int ci
                 if (best.cost < 1e30) out.push_back(best);
             }
         }
+    if (ks == 3 && latency_bound && cin16 >= 64) {
+        // v6: the four waves of a block split the 16-channel blocks of the SAME PT x CT tiles (bit-exact: the canonical order
+        // sums block partials); LDS = halo tile of one chunk + cib x CT x PT partial tiles of 1 KiB
+        static const int use_v6 = env_int("MI355_CONV_V6", 1);
+        const int cib = cin16 / 16;
+        for (int PT = 1; PT <= 2 && use_v6; ++PT)
+            for (int CT = 1; CT <= 2; ++CT) {
+                if (CT > n_ctiles) continue;
+                const int P = PT * 16, nblk = (n_ctiles + CT - 1) / CT;
+                const double waste_c = (double)nblk * CT / n_ctiles;
+                for (int ck = 256; ck >= 64; ck >>= 1) {
+                    if (ck > cin16 && ck != 64) continue;
+                    Plan best{}; best.cost = 1e30;
+                    for (int TW = 1; TW <= P && TW <= W; ++TW) {
+                        int TH = P / TW; if (TH > H) TH = H;
+                        if (TH < 1) continue;
+                        const long tiles = (long)((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+                        const int THin = (TH - 1) * stride + ks, TWin = (TW - 1) * stride + ks;
+                        const int stage_floats = round_up(THin * TWin * (ck + 4), 4);
+                        const size_t lds = (size_t)stage_floats * 4 + (size_t)cib * CT * PT * 1024;
+                        if (lds > LDS_HARD) continue;
+                        const double infl = waste_c * (double)tiles * P / ((double)W * H);
+                        const int stages = (cin16 + ck - 1) / ck;
+                        double cost = infl * (1.0 + 0.04 * (stages - 1)) * latency_factor(sh, tiles * images * nblk, PT, CT, 4);
+                        if (cost < best.cost) best = Plan{CT, 1, TW, TH, ck, lds, cost, 6, stage_floats, PT};
+                    }
+                    if (best.cost < 1e30) out.push_back(best);
+                }
+            }
+    }
     if (ks == 1 && have_zero_page) {        // streaming pointwise kernel (needs the zero page as well): CT x PT register tiles
         static const int use_v3 = env_int("MI355_CONV_V3", 1);
         const int cts[3] = {1, 2, 4}, pts[3] = {2, 4, 1};
@@ -154,7 +185,7 @@ std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int ci
     if (latency_bound) {
         // the latency model is crude: let the timed top-N hold both families, best of each alternating
         std::vector<Plan> big, small, merged;
-        for (const Plan& p : out) ((p.PT == 0 || p.PT >= 4) && !(p.version == 3 && p.buf_floats == 1) ? big : small).push_back(p);
+        for (const Plan& p : out) ((p.PT == 0 || p.PT >= 4) && p.version != 6 && !(p.version == 3 && p.buf_floats == 1) ? big : small).push_back(p);
         for (size_t i = 0; i < std::max(big.size(), small.size()); ++i) {
             if (i < small.size()) merged.push_back(small[i]);
             if (i < big.size()) merged.push_back(big[i]);
@@ -204,7 +235,8 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     KernelFn fn = half ? (p.version == 4 ? (KernelFn)pick_conv_pipe_f16(p.CT, p.WP, (c.Cin + 1) / 2 <= p.ck, p.ck > 64)
                                          : (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.version == 3 ? p.buf_floats : p.PT))
                        : (p.version == 3 ? pick_f32_stream(p.CT, p.buf_floats)
-                          : p.version == 4 ? pick_f32_pipe(p.CT, p.WP, c.Cin <= p.ck, p.ck, p.PT) : pick_kernel(c.k, c.stride, p.CT, p.WP, p.PT));
+                          : p.version == 4 ? pick_f32_pipe(p.CT, p.WP, c.Cin <= p.ck, p.ck, p.PT)
+                          : p.version == 6 ? pick_f32_splitk(c.stride, p.CT, p.PT) : pick_kernel(c.k, c.stride, p.CT, p.WP, p.PT));
     if (!fn) return "conv: no kernel instance";
     a.zeros = c.zeros; a.lds_buf_floats = p.buf_floats;
     if (half && p.version == 4) a.lds_buf_floats = 0;
@@ -218,8 +250,9 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     if (p.version == 4 && a.up_c) { a.inv_TW = 1.0f / (float)c.Win; a.inv_TWin = 1.0f / (float)c.Hin; }   // v4 has no other use for them
     // plans count staged channels in 4-byte units; the fp16 kernels stage twice as many channels in the same bytes
     a.ck = half ? 2 * p.ck : p.ck; a.ldp = half ? a.ck + 8 : a.ck + 4;
-    a.ck4_shift = (p.ck == 128 ? 5 : p.ck == 64 ? 4 : p.ck == 32 ? 3 : 2);
-    const int WC = 4 / p.WP;
+    a.ck4_shift = 0;
+    while ((4 << a.ck4_shift) < p.ck) ++a.ck4_shift;               // log2 of the 16-byte slots per staged pixel
+    const int WC = p.version == 6 ? 1 : 4 / p.WP;
     out->fn = (const void*)fn;
     a.n_tiles_total = (int)((long)B * a.tiles_x * a.tiles_y);
     out->grid_x = (unsigned)a.n_tiles_total;

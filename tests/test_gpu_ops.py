@@ -70,10 +70,12 @@ def test_conv2d_bit_exact_vs_canonical_order_oracle(n, h, w, cin, cout, k, strid
 @pytest.mark.parametrize("n,h,w,cin,cout,k,stride", [
     (2, 24, 40, 64, 64, 3, 1), (1, 40, 40, 80, 80, 3, 1), (2, 16, 16, 128, 256, 3, 2), (3, 20, 20, 384, 128, 1, 1),
     (1, 32, 48, 32, 16, 3, 1), (2, 20, 20, 51, 51, 3, 1), (1, 64, 64, 16, 32, 3, 2), (2, 12, 12, 192, 96, 1, 1),
+    # batch-1 shapes: latency-bound, so the candidates include the small wave tiles and the split-K kernel (v6)
+    (1, 20, 20, 256, 80, 3, 1), (1, 20, 20, 128, 128, 3, 2), (1, 10, 14, 320, 48, 3, 1), (1, 40, 40, 64, 64, 3, 1),
 ])
 def test_every_launch_plan_gives_the_same_bits(n, h, w, cin, cout, k, stride):
-    """All candidate plans (tile shapes, wave arrangements, v1 register-staged / v2 DMA-loader kernels, staged
-    channel counts) must reproduce the canonical-order oracle bit for bit: the autotuner may pick any of them."""
+    """All candidate plans (tile shapes, wave arrangements and wave-tile sizes, LDS-staged / streamed / pipelined / split-K
+    kernels, staged channel counts) must reproduce the canonical-order oracle bit for bit: the autotuner may pick any."""
     from cvsd_amd import ops
     from oracle import det
     rng = np.random.default_rng(cin + cout + k + h)
