@@ -358,6 +358,115 @@ def build_program(family: str = "v8", scale: str = "n", task: str = "detect", nc
     return prog
 
 
+def merge_sibling_convs(prog: Program, fused: Optional[Dict[str, tuple]] = None):
+    """Engine-side optimisation pass: convs that read the SAME input view with the same geometry (the first 3x3 of the
+    box / class / keypoint branches of a head level: ``Detect.cv2[i][0]``, ``cv3[i][0]``, ``Pose.cv4[i][0]``) become ONE conv
+    whose output channels are the concatenation -- the input tile is staged once instead of two or three times and a level
+    costs one launch instead of three.  Every output channel is computed exactly as before (a conv's channels are
+    independent), so results are bit-identical; the consumers simply read channel slices of the shared output buffer.
+
+    Returns ``(program, fused)``: a new Program (unused buffers dropped, indices remapped) and, if ``fused`` (name ->
+    (w, b)) was given, the matching weight dict with the merged entries ``"a+b+c"``.  ``build_program`` itself stays the
+    literal module graph: the oracle, the synthetic checkpoints and the converter work on that.
+    """
+    import copy
+    import numpy as np
+    prog = copy.deepcopy(prog)
+    fused = dict(fused) if fused is not None else None
+    n_ops = len(prog.ops)
+    head_bufs = {lv.buf for lv in prog.levels}
+
+    def writers(buf):
+        return [o for o in prog.ops if o.dst is not None and o.dst.buf == buf]
+
+    groups: Dict[tuple, List[int]] = {}
+    for i, o in enumerate(prog.ops):
+        if o.type != OP_CONV or o.res is not None or o.dst.buf in head_bufs:
+            continue
+        c = prog.convs[o.conv]
+        whole = o.dst.choff == 0 and o.dst.c == prog.buffers[o.dst.buf][0] and len(writers(o.dst.buf)) == 1
+        if not whole:
+            continue
+        groups.setdefault((o.src.buf, o.src.choff, o.src.c, c.k, c.s, c.act, prog.buffers[o.dst.buf][1]), []).append(i)
+    drop_ops, drop_convs, buf_map = set(), set(), {}
+    for key, members in groups.items():
+        if len(members) < 2:
+            continue
+        # slices must start on multiples of 8 channels (16 bytes of fp16): at most one member may have a ragged width, last
+        members = sorted(members, key=lambda i: (prog.convs[prog.ops[i].conv].cout % 8 != 0, i))
+        if sum(prog.convs[prog.ops[i].conv].cout % 8 != 0 for i in members) > 1:
+            continue
+        specs = [prog.convs[prog.ops[i].conv] for i in members]
+        total = sum(c.cout for c in specs)
+        name = "+".join(c.name for c in specs)
+        if len(name) > 63:
+            continue
+        first = prog.ops[members[0]]
+        nb = len(prog.buffers)
+        prog.buffers.append((total, key[6]))
+        off = 0
+        for i, c in zip(members, specs):
+            buf_map[prog.ops[i].dst.buf] = (nb, off)
+            off += c.cout
+        if fused is not None:
+            fused[name] = (np.ascontiguousarray(np.concatenate([fused[c.name][0] for c in specs], 0)),
+                           np.ascontiguousarray(np.concatenate([fused[c.name][1] for c in specs], 0)))
+            for c in specs:
+                del fused[c.name]
+        keep = specs[0]
+        prog.convs[first.conv] = ConvSpec(name, keep.cin, total, keep.k, keep.s, keep.act, keep.has_bn, keep.stride_div)
+        first.dst = View(nb, 0, total)
+        for i in members[1:]:
+            drop_ops.add(i)
+            drop_convs.add(prog.ops[i].conv)
+    if not buf_map:
+        return prog, fused
+    # consumers of the merged-away buffers read slices of the shared one
+    for o in prog.ops:
+        for attr in ("src", "res"):
+            v = getattr(o, attr)
+            if v is not None and v.buf in buf_map:
+                nb, off = buf_map[v.buf]
+                setattr(o, attr, View(nb, off + v.choff, v.c))
+    prog.ops = [o for i, o in enumerate(prog.ops) if i not in drop_ops]
+    conv_new = {}
+    convs2 = []
+    for i, c in enumerate(prog.convs):
+        if i not in drop_convs:
+            conv_new[i] = len(convs2)
+            convs2.append(c)
+    prog.convs = convs2
+    for o in prog.ops:
+        if o.conv >= 0:
+            o.conv = conv_new[o.conv]
+    # drop buffers nothing refers to any more
+    used = set(lv.buf for lv in prog.levels)
+    for o in prog.ops:
+        for v in (o.src, o.dst, o.res):
+            if v is not None:
+                used.add(v.buf)
+    remap, bufs2 = {}, []
+    for i, bdesc in enumerate(prog.buffers):
+        if i in used:
+            remap[i] = len(bufs2)
+            bufs2.append(bdesc)
+    prog.buffers = bufs2
+    for o in prog.ops:                                             # fresh View objects: the builder shares them between ops
+        for attr in ("src", "dst", "res"):
+            v = getattr(o, attr)
+            if v is not None:
+                setattr(o, attr, View(remap[v.buf], v.choff, v.c))
+    for lv in prog.levels:
+        lv.buf = remap[lv.buf]
+    assert len(prog.ops) < n_ops
+    return prog, fused
+
+
+def engine_program(family: str = "v8", scale: str = "n", task: str = "detect", nc: Optional[int] = None) -> Program:
+    """The program the engine actually runs: ``build_program`` + the optimisation passes (for tools that match launches)."""
+    return merge_sibling_convs(build_program(family, scale, task, nc=nc))[0]
+
+
 def parse_model_name(name: str) -> Tuple[str, str, str]:
     """'yolov8n', 'yolov8s-pose', 'yolov5mu' -> (family, scale, task)."""
     n = name.lower().replace(".pt", "").replace(".mi355w", "").replace(".yaml", "")

@@ -30,7 +30,7 @@ from typing import Dict, Tuple
 
 import numpy as np
 
-from .graph import (ACT_NONE, ConvSpec, HeadLevel, Op, Program, View, build_program)
+from .graph import (ACT_NONE, ConvSpec, HeadLevel, Op, Program, View, build_program, merge_sibling_convs)
 
 MAGIC = b"MI355YW1"
 VERSION = 1
@@ -195,4 +195,4 @@ def build_from_state_dict(name: str, sd: Dict[str, np.ndarray], nc: int | None =
     prog = build_program(family, scale, task, nc=nc)
     m = {"model": name}
     m.update(meta or {})
-    return to_bytes(prog, fuse_state_dict(prog, sd), m)
+    return to_bytes(*merge_sibling_convs(prog, fuse_state_dict(prog, sd)), m)

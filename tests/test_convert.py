@@ -58,7 +58,9 @@ def test_convert_fabricated_checkpoint(tmp_path, v8n):
     assert convert.infer_model_name(got, info) == "yolov8n"
     blob = convert.convert_pt(p)
     prog2, fused, meta = weights.from_bytes(blob)
-    assert meta["names"]["0"] == "person" and prog2.nc == 80 and len(prog2.convs) == 63
+    # 63 module convs; the engine program merges the three (cv2[i][0], cv3[i][0]) sibling pairs of the head: 60 launches
+    assert meta["names"]["0"] == "person" and prog2.nc == 80 and len(prog2.convs) == 60
+    assert sum(c.cout * c.cin * c.k * c.k + c.cout for c in prog2.convs) == sum(c.cout * c.cin * c.k * c.k + c.cout for c in prog.convs)
 
 
 def test_infer_model_name_variants():

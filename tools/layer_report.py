@@ -6,14 +6,14 @@ Matches the dispatch sequence of one engine pass (stem, program ops..., decode, 
 prints, per conv launch, the median duration over all passes, achieved TFLOP/s and the layer's algorithmic bytes."""
 import csv, sys, os, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cvsd_amd.graph import build_program, parse_model_name, OP_CONV, OP_STEM, OP_UPSAMPLE, OP_SPPF_POOL
+from cvsd_amd.graph import engine_program, parse_model_name, OP_CONV, OP_STEM, OP_UPSAMPLE, OP_SPPF_POOL
 
 path = sys.argv[1]
 model = sys.argv[2] if len(sys.argv) > 2 else "yolov8n"
 chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 size = int(sys.argv[4]) if len(sys.argv) > 4 else 640
 es = float(sys.argv[5]) if len(sys.argv) > 5 else 4.0      # activation element size: 4 = fp32, 2 = the half=True engine
-prog = build_program(*parse_model_name(model))
+prog = engine_program(*parse_model_name(model))     # the program the engine runs (sibling convs merged)
 sched_log = sys.argv[6] if len(sys.argv) > 6 else None      # bench log with the engine's "[sched] pos op stream launched" lines
 rows = [r for r in csv.DictReader(open(path)) if "mi355" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Dispatch_Id"]))              # host enqueue order (kernels of different streams overlap in time)
@@ -52,7 +52,7 @@ prog_l = [k for k in range(len(prog.ops)) if launched[k]]
 seq = [kind[prog.ops[k].type] for k in prog_l] + tail
 print(f"{len(passes)} passes of {len(seq)} launches matched ({model}, chunk {chunk})")
 tot = 0.0
-print(f"{'op':26s} {'kernel<KS,S,PT,CT,WP>':24s} {'shape':30s} {'grid':>12s} {'lds':>6s} {'vgpr':>5s} {'us':>8s} {'TFLOP/s':>8s} {'GB/s':>7s}")
+print(f"{'op':40s} {'kernel<KS,S,PT,CT,WP>':24s} {'shape':30s} {'grid':>12s} {'lds':>6s} {'vgpr':>5s} {'us':>8s} {'TFLOP/s':>8s} {'GB/s':>7s}")
 for j, name in enumerate(seq):
     d = [(int(p[j]["End_Timestamp"]) - int(p[j]["Start_Timestamp"])) / 1e3 for p in passes]
     us = statistics.median(d); tot += us
@@ -64,10 +64,10 @@ for j, name in enumerate(seq):
         hw = (size // c.stride_div) ** 2
         fl = 2.0 * c.cout * c.cin * c.k * c.k * hw * chunk
         by = es * chunk * (c.cin * hw * c.s * c.s + c.cout * hw)
-        print(f"{c.name:26s} {tmpl:24s} {f'{c.cin}->{c.cout} k{c.k}s{c.s} @{size//c.stride_div}':30s} "
+        print(f"{c.name[:40]:40s} {tmpl:24s} {f'{c.cin}->{c.cout} k{c.k}s{c.s} @{size//c.stride_div}':30s} "
               f"{r['Grid_Size_X'] + 'x' + r['Grid_Size_Y']:>12s} {r['LDS_Block_Size']:>6s} {int(r['VGPR_Count'])+int(r['Accum_VGPR_Count']):>5d} {us:8.1f} {fl / us / 1e6:8.2f} {by / us / 1e3:7.0f}")
     else:
-        print(f"{name:26s} {'':24s} {'':30s} {r['Grid_Size_X'] + 'x' + r['Grid_Size_Y']:>12s} {r['LDS_Block_Size']:>6s} {int(r['VGPR_Count'])+int(r['Accum_VGPR_Count']):>5d} {us:8.1f}")
+        print(f"{name:40s} {'':24s} {'':30s} {r['Grid_Size_X'] + 'x' + r['Grid_Size_Y']:>12s} {r['LDS_Block_Size']:>6s} {int(r['VGPR_Count'])+int(r['Accum_VGPR_Count']):>5d} {us:8.1f}")
 print(f"sum of medians: {tot:.1f} us per pass of {chunk} frames -> {chunk / tot * 1e6:.0f} frames/s device-only")
 # --stats style summary over the matched passes only (the raw rocprofv3 kernel_stats.csv also counts the engine's
 # one-off autotune launches, which are not part of a step)
@@ -77,7 +77,7 @@ for p in passes:
     for r in p:
         kn = r["Kernel_Name"]; kn = kn[:kn.find("(")] if "(" in kn else kn
         agg[kn][0] += 1; agg[kn][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-is_conv = lambda k: "conv_igemm" in k or "conv1x1_" in k
+is_conv = lambda k: "conv_igemm" in k or "conv1x1_" in k or "conv_splitk" in k
 conv_calls = sum(v[0] for k, v in agg.items() if is_conv(k)); conv_us = sum(v[1] for k, v in agg.items() if is_conv(k))
 all_us = sum(v[1] for v in agg.values())
 print(f"\nkernel summary over {len(passes)} real passes:")
