@@ -54,6 +54,10 @@ SIGNATURES = {
                                    _i32p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, _i32p]),
     "mi355_yolo_infer_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                           _i32p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, _i32p]),
+    "mi355_yolo_infer_device_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                                _i32p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_yolo_stream": (C.c_void_p, [C.c_void_p]),
+    "mi355_yolo_sync": (C.c_int, [C.c_void_p]),
     "mi355_yolo_raw_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       _i32p, _i32p]),
     "mi355_yolo_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

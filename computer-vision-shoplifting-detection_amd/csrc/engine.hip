@@ -13,6 +13,8 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace mi355 {
 
@@ -122,8 +124,11 @@ struct mi355_yolo {
     int autotune = 32;                  // candidate launch plans timed per conv when a shape is first seen (0 = off)
     long long n_params = 0, macs640 = 0;
 
-    // per-shape state
-    int cur_nb = 0, cur_H = 0, cur_W = 0;
+    // per-shape state: activation buffers are GROW-ONLY for a letterboxed size (alloc_nb frames); launch plans belong to
+    // (cur_nb, cur_H, cur_W) and are rebuilt -- from the tuned-choice cache, without touching the buffers -- when only the
+    // frame count of a call changes (sweep tails, track() at n = 1 between batched predicts)
+    int cur_nb = 0, cur_H = 0, cur_W = 0, alloc_nb = 0;
+    unsigned long long model_hash = 0;  // FNV-1a of the .mi355w image: key of the persisted plan choices
     std::vector<float*> dbuf;           // activation buffers (fp32, or fp16 bytes behind a float* when `half`)
     std::vector<int> dbuf_cs;           // pixel stride in ELEMENTS of the buffer's dtype
     std::vector<int> dbuf_es;           // element size in bytes: 4, or 2 for the fp16 buffers of the half=True path
@@ -161,6 +166,7 @@ struct mi355_yolo {
     unsigned* d_cmask = nullptr; unsigned* h_cmask = nullptr; int cmask_words = 0;
     int* d_xtab = nullptr; int* d_ytab = nullptr; int tab_h0 = -1, tab_w0 = -1, tab_imgsz = -1;
     float* d_rawhead = nullptr; size_t rawhead_floats = 0;
+    bool async_pending = false;         // mi355_yolo_infer_device_async work may still be in flight on `stream`
     // timing
     bool profiling = false;
     mi355_timing last{};
@@ -180,7 +186,7 @@ void mi355_yolo::free_shape() {
     if (pred) (void)hipFree(pred); if (best) (void)hipFree(best); if (keys) (void)hipFree(keys);
     if (lbox) (void)hipFree(lbox);
     pred = nullptr; best = nullptr; keys = nullptr; lbox = nullptr;
-    cur_nb = cur_H = cur_W = 0;
+    cur_nb = cur_H = cur_W = alloc_nb = 0;
 }
 
 mi355_yolo::~mi355_yolo() {
@@ -225,6 +231,11 @@ static int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
     h->convs.resize(H.n_convs);  std::memcpy(h->convs.data(), blob + p, sizeof(FileConv) * H.n_convs); p += sizeof(FileConv) * H.n_convs;
     h->levels.resize(H.n_levels); std::memcpy(h->levels.data(), blob + p, sizeof(FileLevel) * H.n_levels);
     if (H.nkpt * H.kdim > MI355_MAX_KPT_FLOATS) return fail(MI355_EFORMAT, "keypoint shape larger than 17x3 is not supported");
+    {
+        unsigned long long hsh = 1469598103934665603ull;
+        for (size_t i = 0; i < n; ++i) { hsh ^= blob[i]; hsh *= 1099511628211ull; }
+        h->model_hash = hsh;
+    }
     // validate the program
     for (const FileOp& o : h->ops) {
         auto okv = [&](int b, int off, int c) { return b >= 0 && b < (int)H.n_buffers && off >= 0 && (off & 3) == 0 && off + c <= (int)h->bufs[b].channels; };
@@ -232,6 +243,26 @@ static int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
         if (!okv(o.dst_buf, o.dst_choff, o.type == OP_SPPF_POOL ? 3 * o.src_c : o.dst_c)) return fail(MI355_EFORMAT, "op writes outside its buffer");
         if (o.res_buf >= 0 && !okv(o.res_buf, o.res_choff, o.dst_c)) return fail(MI355_EFORMAT, "residual outside its buffer");
         if ((o.type == OP_STEM || o.type == OP_CONV) && (o.conv < 0 || o.conv >= (int)H.n_convs)) return fail(MI355_EFORMAT, "bad conv index");
+    }
+    {
+        // The multi-stream schedule orders ops by read-after-write only.  That is complete iff every channel of a buffer has
+        // ONE writer and every reader comes after it in program order (no WAW, no WAR): checked here, so that a program
+        // that recycles buffer slices is refused instead of racing silently across streams.
+        auto written = [&](const FileOp& o) { return o.type == OP_SPPF_POOL ? 3 * o.src_c : o.dst_c; };
+        auto overlaps = [](int a0, int ac, int b0, int bc) { return a0 < b0 + bc && b0 < a0 + ac; };
+        for (size_t i = 0; i < h->ops.size(); ++i) {
+            const FileOp& w = h->ops[i];
+            for (size_t j = 0; j < h->ops.size(); ++j) {
+                const FileOp& o = h->ops[j];
+                if (j > i && o.dst_buf == w.dst_buf && overlaps(o.dst_choff, written(o), w.dst_choff, written(w)))
+                    return fail(MI355_EFORMAT, "program writes a buffer slice twice (buffer reuse is not supported)");
+                if (j < i) {
+                    const bool rd = o.type != OP_STEM && o.src_buf == w.dst_buf && overlaps(o.src_choff, o.src_c, w.dst_choff, written(w));
+                    const bool rr = o.res_buf == w.dst_buf && overlaps(o.res_choff, o.dst_c, w.dst_choff, written(w));
+                    if (rd || rr) return fail(MI355_EFORMAT, "program reads a buffer slice before the op that writes it");
+                }
+            }
+        }
     }
     h->n_params = H.reg_max; h->macs640 = 0;
     for (const FileOp& o : h->ops) {
@@ -368,31 +399,98 @@ static int build_schedule(mi355_yolo* h) {
     return MI355_OK;
 }
 
+// ---- persisted launch-plan choices ---------------------------------------------------------------------------
+// Timing 32 candidates x 60-90 convs costs a second or two per (frames, H, W); eight ranks of one node (and every later
+// process) need not repeat it.  The autotuner's CHOICES -- an index into each conv's candidate list -- are kept in a small
+// text file keyed by (model image hash, precision, frames, H, W, planner version); a file whose candidate counts do not
+// match the running planner is ignored.  MI355_PLAN_CACHE=<dir> moves the directory, MI355_PLAN_CACHE=0 turns it off.
+static const char* kPlanVersion = "mi355-plans-r02c";
+
+static std::string plan_cache_path(const mi355_yolo* h, int nb, int Hl, int Wl) {
+    const char* e = getenv("MI355_PLAN_CACHE");
+    if (e && std::strcmp(e, "0") == 0) return std::string();
+    std::string dir;
+    if (e && *e) dir = e;
+    else if (const char* home = getenv("HOME")) dir = std::string(home) + "/.cache/mi355yolo";
+    else dir = "/tmp/mi355yolo";
+    (void)mkdir(dir.substr(0, dir.rfind('/')).c_str(), 0755);
+    (void)mkdir(dir.c_str(), 0755);
+    char name[160];
+    snprintf(name, sizeof(name), "/%016llx_%s_t%d_%dx%dx%d.plan", h->model_hash, h->half ? "f16" : "f32", h->autotune, nb, Hl, Wl);
+    return dir + name;
+}
+
+static bool load_plan_choices(const mi355_yolo* h, int nb, int Hl, int Wl, const std::vector<int>& n_cands, std::vector<int>* chosen) {
+    const std::string path = plan_cache_path(h, nb, Hl, Wl);
+    if (path.empty()) return false;
+    FILE* f = std::fopen(path.c_str(), "r");
+    if (!f) return false;
+    char ver[64] = {0};
+    int n = 0;
+    bool ok = std::fscanf(f, "%63s %d", ver, &n) == 2 && std::strcmp(ver, kPlanVersion) == 0 && n == (int)n_cands.size();
+    std::vector<int> got(n_cands.size(), 0);
+    for (size_t i = 0; ok && i < n_cands.size(); ++i) {
+        int c = 0, nc = 0;
+        ok = std::fscanf(f, "%d/%d", &c, &nc) == 2 && nc == n_cands[i] && c >= 0 && (c < nc || nc == 0);
+        got[i] = c;
+    }
+    std::fclose(f);
+    if (ok) *chosen = got;
+    return ok;
+}
+
+static void save_plan_choices(const mi355_yolo* h, int nb, int Hl, int Wl, const std::vector<int>& n_cands, const std::vector<int>& chosen) {
+    const std::string path = plan_cache_path(h, nb, Hl, Wl);
+    if (path.empty()) return;
+    const std::string tmp = path + "." + std::to_string((long)getpid());
+    FILE* f = std::fopen(tmp.c_str(), "w");
+    if (!f) return;
+    std::fprintf(f, "%s %zu\n", kPlanVersion, n_cands.size());
+    for (size_t i = 0; i < n_cands.size(); ++i) std::fprintf(f, "%d/%d\n", chosen[i], n_cands[i]);
+    std::fclose(f);
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());   // atomic: ranks may race
+}
+
 static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
     if (h->cur_nb == nb && h->cur_H == Hl && h->cur_W == Wl) return MI355_OK;
-    h->free_shape();
     if ((Hl % 32) || (Wl % 32)) return fail(MI355_EINVAL, "letterboxed size must be a multiple of 32");
     const size_t nbufs = h->bufs.size();
-    h->dbuf.assign(nbufs, nullptr); h->dbuf_cs.assign(nbufs, 0); h->dbuf_es.assign(nbufs, 4);
-    for (size_t i = 0; i < nbufs; ++i) {
-        // half=True: every buffer holds fp16 except the head outputs (raw box / class / keypoint logits), which the
-        // final 1x1 convs write in fp32 for the decode kernel
-        bool is_head = false;
-        for (const FileLevel& lv : h->levels) is_head |= (lv.buf == i);
-        const int es = (h->half && !is_head) ? 2 : 4;
-        const int cs = round_up((int)h->bufs[i].channels, 16 / es);
-        h->dbuf_es[i] = es;
-        const size_t bytes = (size_t)nb * (Hl / h->bufs[i].stride_div) * (Wl / h->bufs[i].stride_div) * cs * es;
-        HIPCHK(hipMalloc(&h->dbuf[i], bytes));
-        HIPCHK(hipMemsetAsync(h->dbuf[i], 0, bytes, h->stream));   // pad channels stay zero forever
-        h->dbuf_cs[i] = cs;
+    if (h->cur_H != Hl || h->cur_W != Wl || nb > h->alloc_nb) {
+        // (re)allocate: a new letterboxed size, or more frames per pass than the buffers hold
+        h->free_shape();
+        h->dbuf.assign(nbufs, nullptr); h->dbuf_cs.assign(nbufs, 0); h->dbuf_es.assign(nbufs, 4);
+        for (size_t i = 0; i < nbufs; ++i) {
+            // half=True: every buffer holds fp16 except the head outputs (raw box / class / keypoint logits), which the
+            // final 1x1 convs write in fp32 for the decode kernel
+            bool is_head = false;
+            for (const FileLevel& lv : h->levels) is_head |= (lv.buf == i);
+            const int es = (h->half && !is_head) ? 2 : 4;
+            const int cs = round_up((int)h->bufs[i].channels, 16 / es);
+            h->dbuf_es[i] = es;
+            const size_t bytes = (size_t)nb * (Hl / h->bufs[i].stride_div) * (Wl / h->bufs[i].stride_div) * cs * es;
+            HIPCHK(hipMalloc(&h->dbuf[i], bytes));
+            HIPCHK(hipMemsetAsync(h->dbuf[i], 0, bytes, h->stream));   // pad channels stay zero forever
+            h->dbuf_cs[i] = cs;
+        }
+        int A = 0;
+        for (const FileLevel& lv : h->levels) A += (Hl / lv.stride) * (Wl / lv.stride);
+        h->A = A; h->Apow2 = 1; while (h->Apow2 < A) h->Apow2 <<= 1;
+        HIPCHK(hipMalloc(&h->pred, (size_t)nb * A * h->no() * 4));
+        HIPCHK(hipMalloc(&h->best, (size_t)nb * A * sizeof(float2)));
+        HIPCHK(hipMalloc(&h->keys, (size_t)nb * h->Apow2 * 8));
+        HIPCHK(hipMalloc(&h->lbox, (size_t)nb * Hl * Wl * 3));
+        h->alloc_nb = nb; h->cur_H = Hl; h->cur_W = Wl;
     }
+    // ---- launch plans for nb frames per pass on the existing buffers ----
+    for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.second);      // captured launches embed the old plans
+    h->graphs.clear();
     h->plans.assign(h->ops.size(), ConvLaunch{});
     const bool tune_log = getenv("MI355_TUNE_LOG") != nullptr;
     const std::array<int, 3> shape_key{nb, Hl, Wl};
-    const std::vector<int>* cached = nullptr;
-    for (const auto& t : h->tuned) if (t.first == shape_key) cached = &t.second;
-    std::vector<int> chosen(h->ops.size(), 0);
+    // pass 1: the candidate lists (host work only)
+    std::vector<std::vector<ConvLaunch>> cands(h->ops.size());
+    std::vector<ConvArgs> cargs(h->ops.size());
+    std::vector<int> n_cands(h->ops.size(), 0);
     for (size_t i = 0; i < h->ops.size(); ++i) {
         const FileOp& o = h->ops[i];
         if (o.type != OP_CONV) continue;
@@ -411,7 +509,6 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
         a.B = nb; a.Hin = Hl / sd_in; a.Win = Wl / sd_in; a.Hout = Hl / sd_out; a.Wout = Wl / sd_out;
         a.Cin = c.cin; a.Cout = c.cout; a.k = c.k; a.stride = c.s; a.pad = c.pad; a.act = c.act;
         if (a.Hout * (int)c.s != a.Hin || a.Wout * (int)c.s != a.Win) return fail(MI355_EFORMAT, "conv resolution mismatch in program");
-        std::vector<ConvLaunch> cands;
         if (h->fuse_up[i] >= 0) {
             const FileOp& u = h->ops[h->fuse_up[i]];
             ConvArgs f = a;
@@ -419,54 +516,66 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
             const bool same_prec = h->dbuf_es[u.src_buf] == h->dbuf_es[o.src_buf];
             const bool shape_ok = h->bufs[u.src_buf].stride_div == 2 * sd_in && (a.Hin % 2) == 0 && (a.Win % 2) == 0 &&
                                   (u.src_c % (16 / h->dbuf_es[o.src_buf])) == 0;
-            if (same_prec && shape_ok && plan_conv_candidates(f, &cands) == nullptr && !cands.empty()) {
+            if (same_prec && shape_ok && plan_conv_candidates(f, &cands[i]) == nullptr && !cands[i].empty()) {
                 a = f;
                 h->fused_away[h->fuse_up[i]] = 1;
             } else {                                    // no v4 plan for this shape: run the upsample kernel after all
-                cands.clear();
+                cands[i].clear();
                 h->fused_away[h->fuse_up[i]] = 0;
             }
         }
-        if (cands.empty()) KCHK(plan_conv_candidates(a, &cands));
-        h->plans[i] = cands[0];
-        if (cached && (size_t)(*cached)[i] < cands.size()) {
-            h->plans[i] = cands[(*cached)[i]];
-        } else if (h->autotune && cands.size() > 1) {
+        if (cands[i].empty()) KCHK(plan_conv_candidates(a, &cands[i]));
+        cargs[i] = a;
+        n_cands[i] = (int)std::min<size_t>(cands[i].size(), (size_t)std::max(1, h->autotune));
+        h->plans[i] = cands[i][0];
+    }
+    // pass 2: choices -- this process's memory, then the plan file, then the stopwatch
+    std::vector<int> chosen(h->ops.size(), 0);
+    bool have = false;
+    for (const auto& t : h->tuned) if (t.first == shape_key) { chosen = t.second; have = true; }
+    if (!have && h->autotune) have = load_plan_choices(h, nb, Hl, Wl, n_cands, &chosen);
+    if (have) {
+        for (size_t i = 0; i < h->ops.size(); ++i)
+            if (h->ops[i].type == OP_CONV && (size_t)chosen[i] < cands[i].size()) h->plans[i] = cands[i][chosen[i]];
+    } else if (h->autotune) {
+        for (size_t i = 0; i < h->ops.size(); ++i) {
+            const FileOp& o = h->ops[i];
+            if (o.type != OP_CONV || cands[i].size() < 2) continue;
+            const FileConv& c = h->convs[o.conv];
+            const ConvArgs& a = cargs[i];
             // Time the most promising launch plans on the real buffers (outputs are overwritten by the next real
             // pass; the accumulation order is plan-independent, so the choice cannot change results).
-            const size_t ncand = std::min<size_t>(cands.size(), (size_t)h->autotune);
             float best_ms = 1e30f;
-            for (size_t k = 0; k < ncand; ++k) {
+            for (int k = 0; k < n_cands[i]; ++k) {
                 float ms = 1e30f;
                 for (int rep = 0; rep < 3; ++rep) {
                     HIPCHK(hipEventRecord(h->ev0, h->stream));
-                    KCHK(run_conv(cands[k], h->stream));
+                    KCHK(run_conv(cands[i][k], h->stream));
                     HIPCHK(hipEventRecord(h->ev1, h->stream));
                     HIPCHK(hipEventSynchronize(h->ev1));
                     float t = 0.f;
                     HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
                     if (rep > 0) ms = std::min(ms, t);          // first run warms the instruction cache
                 }
-                if (ms < best_ms) { best_ms = ms; h->plans[i] = cands[k]; chosen[i] = (int)k; }
+                if (ms < best_ms) { best_ms = ms; h->plans[i] = cands[i][k]; chosen[i] = k; }
                 if (tune_log)
                     fprintf(stderr, "[tune] %-22s %4u->%-4u k%u s%u @%dx%d  v%d CT%d PT%d WP%d tile %dx%d ck%d lds %zu grid %ux%u : %.1f us  %.1f TFLOP/s\n",
-                            c.name, c.cin, c.cout, c.k, c.s, a.Hout, a.Wout, cands[k].version, cands[k].CT, cands[k].PT, cands[k].WP, cands[k].a.TW,
-                            cands[k].a.TH, cands[k].a.ck, cands[k].lds, cands[k].grid_x, cands[k].grid_y, ms * 1e3,
-                            cands[k].flops / (ms * 1e-3) / 1e12);
+                            c.name, c.cin, c.cout, c.k, c.s, a.Hout, a.Wout, cands[i][k].version, cands[i][k].CT, cands[i][k].PT, cands[i][k].WP, cands[i][k].a.TW,
+                            cands[i][k].a.TH, cands[i][k].a.ck, cands[i][k].lds, cands[i][k].grid_x, cands[i][k].grid_y, ms * 1e3,
+                            cands[i][k].flops / (ms * 1e-3) / 1e12);
             }
             if (tune_log) fprintf(stderr, "[tune] -> v%d CT%d PT%d WP%d tile %dx%d ck%d : %.1f us\n", h->plans[i].version, h->plans[i].CT,
                                   h->plans[i].PT, h->plans[i].WP, h->plans[i].a.TW, h->plans[i].a.TH, h->plans[i].a.ck, best_ms * 1e3);
         }
+        h->tuned.push_back({shape_key, chosen});
+        save_plan_choices(h, nb, Hl, Wl, n_cands, chosen);
     }
-    if (!cached && h->autotune) h->tuned.push_back({shape_key, chosen});
-    int A = 0;
-    for (const FileLevel& lv : h->levels) A += (Hl / lv.stride) * (Wl / lv.stride);
-    h->A = A; h->Apow2 = 1; while (h->Apow2 < A) h->Apow2 <<= 1;
-    HIPCHK(hipMalloc(&h->pred, (size_t)nb * A * h->no() * 4));
-    HIPCHK(hipMalloc(&h->best, (size_t)nb * A * sizeof(float2)));
-    HIPCHK(hipMalloc(&h->keys, (size_t)nb * h->Apow2 * 8));
-    HIPCHK(hipMalloc(&h->lbox, (size_t)nb * Hl * Wl * 3));
-    h->cur_nb = nb; h->cur_H = Hl; h->cur_W = Wl;
+    if (have) {
+        bool known = false;
+        for (const auto& t : h->tuned) known |= (t.first == shape_key);
+        if (!known) h->tuned.push_back({shape_key, chosen});
+    }
+    h->cur_nb = nb;
     if (getenv("MI355_SCHED_LOG")) {      // launch order of a pass for tools/layer_report.py: position, op index, stream, launched
         for (size_t pos = 0; pos < h->sched_order.size(); ++pos) {
             const int idx = h->sched_order[pos];
@@ -612,7 +721,12 @@ static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, c
         for (int idx : h->sched_order) {
             const int sid = h->op_stream[idx];
             hipStream_t st = sid == 0 ? h->stream : h->aux[sid - 1];
-            for (int dep : h->op_xdeps[idx]) HIPCHK(hipStreamWaitEvent(st, h->op_done[dep], 0));
+            for (int dep : h->op_xdeps[idx]) {
+                // an upsample fused into its consumer's read side is never launched (its event is never recorded): the
+                // consumer already depends on the upsample's SOURCE producer (build_schedule)
+                if (h->ops[dep].type == OP_UPSAMPLE && h->fused_away[dep]) continue;
+                HIPCHK(hipStreamWaitEvent(st, h->op_done[dep], 0));
+            }
             const int rc = launch_op((size_t)idx, st); if (rc) return rc;
             if (h->op_signals[idx] && !(h->ops[idx].type == OP_UPSAMPLE && h->fused_away[idx])) HIPCHK(hipEventRecord(h->op_done[idx], st));
         }
@@ -671,10 +785,15 @@ static int collect_timing(mi355_yolo* h, Prof& pf, int frames) {
     return MI355_OK;
 }
 
+// dev_rows != nullptr: the asynchronous device-output form (packed rows, counts and the row total stay in the caller's
+// DEVICE buffers; nothing is copied to the host and the call returns with the work enqueued on the engine's stream)
 static int infer_impl(mi355_yolo* h, const uint8_t* src, bool src_on_device, int n, int height, int width, int row_stride,
                       float conf, float iou, const int* classes, int n_classes, int max_det, int imgsz,
-                      mi355_det* out_rows, int cap, int* out_counts) {
-    if (!h || !src || !out_rows || !out_counts) return fail(MI355_EINVAL, "null argument");
+                      mi355_det* out_rows, int cap, int* out_counts, mi355_det* dev_rows = nullptr, int* dev_counts = nullptr,
+                      int* dev_total = nullptr) {
+    const bool async_out = dev_rows != nullptr;
+    if (!h || !src || (!async_out && (!out_rows || !out_counts)) || (async_out && (!dev_counts || !dev_total)))
+        return fail(MI355_EINVAL, "null argument");
     if (n <= 0 || height <= 0 || width <= 0) return fail(MI355_EINVAL, "n, height and width must be positive");
     if (max_det <= 0) max_det = 300;
     if (max_det > 1024) return fail(MI355_EINVAL, "max_det must be <= 1024");
@@ -685,6 +804,10 @@ static int infer_impl(mi355_yolo* h, const uint8_t* src, bool src_on_device, int
     if (row_stride < width * 3) return fail(MI355_EINVAL, "row_stride_bytes smaller than a row");
     if (n_classes < 0 || (n_classes > 0 && !classes)) return fail(MI355_EINVAL, "bad classes argument");
     HIPCHK(hipSetDevice(h->device));
+    if (h->async_pending) {             // an asynchronous call may still be reading the per-call scratch (class mask, row slots)
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->async_pending = false;
+    }
     const Geometry g = make_geometry(height, width, imgsz);
     const int nb = std::min(n, h->chunk);
     int rc = ensure_shape(h, nb, g.Hl, g.Wl); if (rc) return rc;
@@ -727,7 +850,7 @@ static int infer_impl(mi355_yolo* h, const uint8_t* src, bool src_on_device, int
         if (h->d_offsets) (void)hipFree(h->d_offsets); h->d_offsets = nullptr; h->offsets_cap = 0;
         HIPCHK(hipMalloc(&h->d_offsets, (size_t)(n + 1) * sizeof(int))); h->offsets_cap = n + 1;
     }
-    if (h->h_rows_cap < (size_t)n * max_det) {
+    if (!async_out && h->h_rows_cap < (size_t)n * max_det) {
         if (h->h_rows) (void)hipHostFree(h->h_rows); h->h_rows = nullptr; h->h_rows_cap = 0;
         HIPCHK(hipHostMalloc(&h->h_rows, (size_t)n * max_det * sizeof(mi355_det))); h->h_rows_cap = (size_t)n * max_det;
     }
@@ -789,6 +912,14 @@ static int infer_impl(mi355_yolo* h, const uint8_t* src, bool src_on_device, int
         pf.end();
     }
     HIPCHK(hipEventRecord(h->ev1, h->stream));
+    if (async_out) {
+        // packed rows (frame order), counts and their sum go to the caller's device buffers; no host copy, no sync
+        KCHK(launch_compact_rows(h->d_rows, h->d_counts, n, max_det, (int)(sizeof(mi355_det) / 4), h->d_offsets, dev_rows, h->stream));
+        HIPCHK(hipMemcpyAsync(dev_counts, h->d_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(dev_total, h->d_offsets + n, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+        h->async_pending = true;
+        return MI355_OK;
+    }
     // rows -> host: compact on the GPU first (a frame keeps counts[i] of its max_det slots; copying the slots would be 35 MB
     // per 512 frames), then two small copies: the counts, and sum(counts) rows
     KCHK(launch_compact_rows(h->d_rows, h->d_counts, n, max_det, (int)(sizeof(mi355_det) / 4), h->d_offsets, h->d_packed, h->stream));
@@ -891,6 +1022,24 @@ int mi355_yolo_infer(mi355_yolo* h, const uint8_t* bgr, int n, int height, int w
 int mi355_yolo_infer_device(mi355_yolo* h, const uint8_t* bgr_dev, int n, int height, int width, float conf, float iou,
                             const int* classes, int n_classes, int max_det, int imgsz, mi355_det* out_rows, int cap, int* out_counts) {
     return infer_impl(h, bgr_dev, true, n, height, width, 0, conf, iou, classes, n_classes, max_det, imgsz, out_rows, cap, out_counts);
+}
+
+int mi355_yolo_infer_device_async(mi355_yolo* h, const uint8_t* bgr_dev, int n, int height, int width, float conf, float iou,
+                                  const int* classes, int n_classes, int max_det, int imgsz, mi355_det* rows_dev, int* counts_dev,
+                                  int* total_dev) {
+    if (!rows_dev) return fail(MI355_EINVAL, "null argument");
+    return infer_impl(h, bgr_dev, true, n, height, width, 0, conf, iou, classes, n_classes, max_det, imgsz, nullptr, 1, nullptr,
+                      rows_dev, counts_dev, total_dev);
+}
+
+void* mi355_yolo_stream(mi355_yolo* h) { return h ? (void*)h->stream : nullptr; }
+
+int mi355_yolo_sync(mi355_yolo* h) {
+    if (!h) return fail(MI355_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->async_pending = false;
+    return MI355_OK;
 }
 
 int mi355_yolo_set_profiling(mi355_yolo* h, int on) {

@@ -82,3 +82,59 @@ def gather_rows(rows: np.ndarray, counts: np.ndarray, dst: int = 0, ncols: Optio
     if rank != dst:
         return None, None
     return ([b[:t].cpu().numpy() for b, t in zip(bufs, totals)], [x.cpu().numpy() for x in all_c])
+
+
+class DeviceRowGather:
+    """C2 + C3 for rows that STAY in HBM (``YOLO.infer_async``): the collectives read the engine's device buffers directly
+    and run one step behind the engine, so step k's gather overlaps step k+1's kernels.
+
+        g = DeviceRowGather(model, n_frames)          # double-buffered outputs
+        for k in range(steps):
+            done = g.submit(frames)                   # enqueue step k; returns step k-1's gathered rows (rank 0) or None
+        last = g.flush()
+
+    With ``nccl`` (RCCL over xGMI) nothing touches the host except rank 0's final copy of the gathered block; with ``gloo``
+    (CPU tests) the device buffers are staged through the host -- same call sequence, same result."""
+
+    def __init__(self, model, n_frames: int, max_det: int = 300, ncols: Optional[int] = None, dst: int = 0, **infer_kw):
+        self.model, self.n, self.max_det, self.dst, self.kw = model, n_frames, max_det, dst, infer_kw
+        self.ncols = ncols
+        self.bufs = [model.new_device_rows(n_frames, max_det) for _ in range(2)]
+        self.pending = None
+        self.k = 0
+
+    def _collect(self, item):
+        out, ready = item
+        rows, counts, total = out
+        torch.cuda.current_stream().wait_event(ready)                    # the engine has passed THIS step (not the next one)
+        world = dist.get_world_size() if is_dist() else 1
+        nccl = is_dist() and dist.get_backend() == "nccl"
+        if not is_dist():
+            t = int(total.item())
+            r = rows[:t] if self.ncols is None else rows[:t, :self.ncols]
+            return [r.cpu().numpy()], [counts.cpu().numpy()]
+        c = counts if nccl else counts.cpu()
+        all_c = [torch.empty_like(c) for _ in range(world)]
+        dist.all_gather(all_c, c)                                        # C2
+        totals = [int(x.sum().item()) for x in all_c]
+        m = max(max(totals), 1)
+        block = rows[:m] if self.ncols is None else rows[:m, :self.ncols]
+        block = block.contiguous() if nccl else block.cpu().contiguous()
+        recv = [torch.empty_like(block) for _ in range(world)] if dist.get_rank() == self.dst else None
+        dist.gather(block, recv, dst=self.dst)                           # C3
+        if dist.get_rank() != self.dst:
+            return None, None
+        return [b[:t].cpu().numpy() for b, t in zip(recv, totals)], [x.cpu().numpy() for x in all_c]
+
+    def submit(self, frames):
+        out = self.bufs[self.k & 1]
+        self.k += 1
+        self.model.infer_async(frames, out, max_det=self.max_det, **self.kw)
+        ready = torch.cuda.Event()
+        ready.record(self.model.stream)
+        prev, self.pending = self.pending, (out, ready)
+        return self._collect(prev) if prev is not None else None
+
+    def flush(self):
+        prev, self.pending = self.pending, None
+        return self._collect(prev) if prev is not None else None

@@ -169,6 +169,45 @@ class YOLO:
                                             imgsz, rows.ctypes.data, max_det, cp))
         return rows, counts, (h, w)
 
+    # ---- device-resident results (multi-GPU pipelines): nothing crosses PCIe, nothing blocks --------------------------
+    def new_device_rows(self, n: int, max_det: int = 300):
+        """Output buffers for :meth:`infer_async`: (rows [n*max_det, 58] f32, counts [n] i32, total [1] i32) on the engine's GPU."""
+        dev = torch.device("cuda", self.device)
+        return (torch.empty((n * max_det, _lib.DET_WORDS), dtype=torch.float32, device=dev),
+                torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+
+    def infer_async(self, frames: torch.Tensor, out, conf: float = 0.25, iou: float = 0.7, classes=None, max_det: int = 300,
+                    imgsz: int = 640, half=None) -> None:
+        """Enqueue one batch of CUDA-resident uint8 frames [n,H,W,3]; the packed post-NMS rows (frame order), the per-frame
+        counts and their sum land in ``out`` (from :meth:`new_device_rows`) -- all in HBM.  Returns at once; order other
+        streams behind :attr:`stream` (or call :meth:`sync`) before reading ``out``."""
+        rows, counts, total = out
+        n, h, w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+        if not frames.is_cuda or frames.dtype != torch.uint8 or frames.device.index != self.device:
+            raise ValueError("infer_async needs uint8 frames on the engine's GPU")
+        if rows.shape[0] < n * max_det or counts.numel() < n:
+            raise ValueError("output buffers are too small for n * max_det rows")
+        cls_arr, ncls = None, 0
+        if classes is not None:
+            cl = [int(classes)] if np.isscalar(classes) else [int(c) for c in classes]
+            cls_arr, ncls = (C.c_int * len(cl))(*cl), len(cl)
+        hnd = self._handle(half)
+        with self._lock:
+            torch.cuda.current_stream(frames.device).synchronize()       # the frames must be complete; the engine has its own stream
+            _lib.check(_lib.lib().mi355_yolo_infer_device_async(hnd, frames.data_ptr(), n, h, w, float(conf), float(iou), cls_arr, ncls,
+                                                                int(max_det), int(imgsz), rows.data_ptr(), counts.data_ptr(),
+                                                                total.data_ptr()))
+
+    @property
+    def stream(self) -> "torch.cuda.ExternalStream":
+        """The engine's HIP stream as a torch stream (``torch.cuda.current_stream().wait_stream(model.stream)``)."""
+        if getattr(self, "_ext_stream", None) is None:
+            self._ext_stream = torch.cuda.ExternalStream(int(_lib.lib().mi355_yolo_stream(self._h)), device=torch.device("cuda", self.device))
+        return self._ext_stream
+
+    def sync(self) -> None:
+        _lib.check(_lib.lib().mi355_yolo_sync(self._h))
+
     def predict(self, source=None, conf: Optional[float] = None, iou: float = 0.7, classes=None, max_det: int = 300,
                 imgsz: int = 640, half: Optional[bool] = None, verbose: bool = False, stream: bool = False, **kwargs
                 ) -> List[Results]:

@@ -119,6 +119,21 @@ int  mi355_yolo_infer_device(mi355_yolo* h, const uint8_t* bgr_nhwc_dev, int n, 
                              float conf, float iou, const int* classes, int n_classes, int max_det, int imgsz,
                              mi355_det* out_rows, int out_capacity_per_image, int* out_counts);
 
+/* Asynchronous device-output form (multi-GPU pipelines: the per-rank rows are gathered over RCCL straight from HBM while the
+ * next batch computes; replaces the reference's per-frame `results[0].boxes` hand-over, model.py:40, for a whole shard).
+ * Frames AND outputs live in DEVICE memory owned by the caller; nothing crosses PCIe and the call returns as soon as the work
+ * is enqueued on the engine's stream:
+ *   rows_dev    [n * max_det] rows, PACKED in frame order: frame 0's counts[0] rows, then frame 1's, ...
+ *   counts_dev  [n] rows kept per frame;   total_dev [1] = sum(counts) = number of valid packed rows
+ * The buffers are valid once the stream has passed this call: wait with mi355_yolo_sync(), or order another HIP stream
+ * behind mi355_yolo_stream() (a hipStream_t; e.g. torch.cuda.ExternalStream).  The next infer call on the handle waits for
+ * a pending asynchronous one before it reuses the engine's scratch, so callers double-buffer the output buffers only. */
+int  mi355_yolo_infer_device_async(mi355_yolo* h, const uint8_t* bgr_nhwc_dev, int n, int height, int width,
+                                   float conf, float iou, const int* classes, int n_classes, int max_det, int imgsz,
+                                   mi355_det* rows_dev, int* counts_dev, int* total_dev);
+void* mi355_yolo_stream(mi355_yolo* h);
+int  mi355_yolo_sync(mi355_yolo* h);
+
 /* The decoded pre-NMS head tensor, exactly the layout Detect/Pose.forward returns: out[n][4+nc+nk][A] fp32
  * (xywh in letterboxed pixels, sigmoid class scores, decoded keypoints).  For parity tests.
  * out may be NULL to query *out_channels / *out_anchors for the given frame size. */

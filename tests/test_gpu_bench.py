@@ -42,3 +42,60 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
     d = _last_json(p.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
     assert d["config"]["global_batch"] == 16
+
+
+def test_async_device_rows_equal_the_blocking_call(v8n):
+    """mi355_yolo_infer_device_async: packed rows / counts / total left in HBM == what the blocking entry point returns"""
+    import numpy as np
+    import torch
+    from cvsd_amd import YOLO, _lib
+    from tools import synth
+    m = YOLO.from_state_dict("yolov8n", v8n[1], batch_chunk=4)
+    frames = torch.from_numpy(synth.synthetic_frames(6, 320, 320, seed=9)).cuda()
+    rows, counts, _ = m._infer_rows(frames, 0.25, 0.7, None, 300, 320)
+    out = m.new_device_rows(6)
+    m.infer_async(frames, out, conf=0.25, iou=0.7, imgsz=320)
+    m.infer_async(frames, out, conf=0.25, iou=0.7, imgsz=320)          # a second call waits for the first before reusing scratch
+    torch.cuda.current_stream().wait_stream(m.stream)
+    torch.cuda.synchronize()
+    d_rows, d_counts, d_total = (t.cpu().numpy() for t in out)
+    np.testing.assert_array_equal(d_counts, counts)
+    assert int(d_total[0]) == int(counts.sum()) > 0
+    want = np.concatenate([rows[i, :counts[i]] for i in range(6)])
+    np.testing.assert_array_equal(d_rows[:len(want)].view(np.uint32), want.view(np.uint32))
+
+
+def test_rccl_world_of_one_with_the_engine_stream():
+    """RCCL (backend 'nccl') initialises on this box and its collectives consume buffers produced on the engine's own
+    non-blocking stream (event-ordered): the plumbing the 8-GPU run relies on, exercised with the one rank a 1-GPU box allows."""
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from cvsd_amd import YOLO
+from tools import synth
+_, sd = synth.synthetic_checkpoint("yolov8n", seed=0)
+m = YOLO.from_state_dict("yolov8n", sd, batch_chunk=4)
+frames = torch.from_numpy(synth.synthetic_frames(4, 320, 320, seed=9)).cuda()
+out = m.new_device_rows(4)
+m.infer_async(frames, out, imgsz=320)
+ev = torch.cuda.Event(); ev.record(m.stream)
+torch.cuda.current_stream().wait_event(ev)
+rows, counts, total = out
+got = [torch.empty_like(counts)]
+dist.all_gather(got, counts)
+blk = rows[:max(int(counts.sum().item()), 1)].contiguous()
+recv = [torch.empty_like(blk)]
+dist.gather(blk, recv, dst=0)
+w = torch.full((1 << 20,), 7, dtype=torch.uint8, device="cuda"); dist.broadcast(w, 0)
+torch.cuda.synchronize()
+ref_rows, ref_counts, _ = m._infer_rows(frames, 0.25, 0.7, None, 300, 320)
+assert np.array_equal(got[0].cpu().numpy(), ref_counts) and int(total.item()) == int(ref_counts.sum())
+assert np.array_equal(recv[0].cpu().numpy().view(np.uint32)[:int(total.item())], np.concatenate([ref_rows[i, :ref_counts[i]] for i in range(4)]).view(np.uint32))
+dist.destroy_process_group()
+print("RCCL_OK", dist.is_nccl_available())
+'''
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
