@@ -27,6 +27,9 @@ struct ConvArgs {
     // `src2`, a map of half the resolution (pixel (y/2, x/2), stride src2_cs), channels >= up_c from `src` as usual --
     // torch.nn.Upsample + Concat + Conv1x1 of the neck without the upsampled tensor ever being written.
     const float* src2 = nullptr; int src2_cs = 0, up_c = 0;
+    // A pointwise conv fused behind this one (3x3 convs, fp32): Cout2 channels from packed weights w2 / bias2 into dst2; this
+    // conv's own dst is then not written (its only reader is that 1x1).  f2_cout = 0: no fusion.
+    const float* f2_wpk = nullptr; const float* f2_bias = nullptr; float* f2_dst = nullptr; int f2_dst_cs = 0, f2_cout = 0, f2_act = 0;
 };
 // number of floats pack_conv_weights writes: ceil(cout/16) * k*k * ceil(cin/16) * 256
 size_t packed_weight_floats(int cout, int cin, int k);
@@ -55,7 +58,10 @@ struct ConvKArgs {
     const float* zeros;        // >= 16 bytes of zeros: what out-of-image / beyond-Cin slots read (loads stay unconditional)
     int out_f32;               // fp16 kernels: destination (and residual) hold fp32
     const float* src2; int src2_cs, up_c, up_W, up_H;   // fused upsample-on-read (v4): full-resolution W, H of the conv input
-    int lds_buf_floats;        // fp16 what-if builds only (-DMI355_F16_DIAG): experiment flags; 0 in product launches
+    int lds_buf_floats;        // fp32: float offset of the second LDS region (split-K partials / fused-1x1 image); fp16 -DMI355_F16_DIAG: flags
+    int cgroups;               // conv_igemm_f32: groups of CT cout tiles a wave walks over one staged input (>= 1)
+    // conv_igemm_f32<..., F2 = true>: the pointwise conv fused behind this one (packed weights, bias, destination slice)
+    const float* w2; const float* bias2; float* dst2; int dst2_cs, Cout2, n_ctiles2, cib2, act2, ldp2;
     int n_tiles_total;         // B * tiles_x * tiles_y (persistent kernels walk tiles blockIdx.x, + gridDim.x, ...)
 };
 // A planned launch: kernel instance, grid, LDS bytes and kernel arguments.  Planning (tile / wave-arrangement

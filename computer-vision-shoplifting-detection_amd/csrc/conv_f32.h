@@ -85,7 +85,33 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x4 (&acc)[C
     }
 }
 
-template <int KS, int STRIDE, int PT, int CT, int WP>
+// One tile's worth of output for ONE cout tile: bias + activation (+ residual) and the 16-byte store (scalar tail when the
+// channel count is not a multiple of 4).  Used by the fused second stage and the split-K finalizer.
+__device__ __forceinline__ void store_tile(f32x4 v, const float* bias, int act, const float* res, int res_cs, float* dst, int dst_cs,
+                                           int cout, int ctile, int lane, size_t po, bool ok) {
+    const int c = ctile * 16 + (lane >> 4) * 4;
+    if (!ok || c >= cout) return;
+    v += *(const f32x4*)(bias + c);
+    if (act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+    float* d = dst + po * dst_cs + c;
+    if (c + 3 < cout) {
+        if (res) v += *(const f32x4*)(res + po * res_cs + c);
+        *(f32x4*)d = v;
+    } else {
+        for (int i = 0; i < 4 && c + i < cout; ++i) {
+            float r = v[i];
+            if (res) r += res[po * res_cs + c + i];
+            d[i] = r;
+        }
+    }
+}
+
+// F2 = a pointwise conv fused behind this one (Conv3x3 -> SiLU -> Conv1x1 whose only reader is that 1x1: the stride-2
+// convs in front of every C2f, and the last two convs of every head branch): the block keeps its PT*WP*16 output pixels x ALL
+// of the first conv's channels in LDS ([pixel][channel], exactly the image a 1x1 kernel would have staged from HBM), and
+// the same four waves then run the 1x1 from there -- the intermediate tensor is never written to or read from HBM.
+// Values, operation order and therefore bits are those of the two separate launches.
+template <int KS, int STRIDE, int PT, int CT, int WP, bool F2 = false>
 __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int WC = 4 / WP;
@@ -98,7 +124,6 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
     const int b = t / a.tiles_y;
     const int oy0 = ty * a.TH, ox0 = tx * a.TW;
     const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
-    const int ct0 = (blockIdx.y * WC + wc) * CT;
     const int npix = a.TW * a.TH;
     int xoff[PT];
 #pragma unroll
@@ -109,164 +134,227 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
         const int lx = p - ly * a.TW;
         xoff[pt] = ((ly * STRIDE) * a.TWin + lx * STRIDE) * a.ldp + (lane >> 4) * 4;
     }
-    // canonical accumulation: `acc` is the fma chain of ONE 16-channel block (all taps), started from +0;
-    // `tot` is the running sum of the block partials in block order
-    f32x4 acc[CT][PT], tot[CT][PT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) tot[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     const float* srcb = a.src + (size_t)b * a.Hin * a.Win * a.src_cs;
-    // cout tiles beyond the last one re-read the last tile's weights (their outputs are discarded by the epilogue):
-    // no branch around the fragment loads, so hipcc keeps a counted s_waitcnt vmcnt(N) and the prefetch stays in flight
-    const float* wbase[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
-        wbase[ct] = a.wpk + (size_t)ctile * TAPS * a.cib * 256 + lane * 4;
-    }
-    // the bias of this lane's 4 couts per cout tile is fetched now (the load's L2 latency hides under the staging) and
-    // not in the epilogue, where it would sit on the block's critical path
-    f32x4 bias4[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
-        bias4[ct] = *(const f32x4*)(a.bias + ctile * 16 + (lane >> 4) * 4);
-    }
     const int ck4m = (a.ck >> 2) - 1;
     const int total_f4 = a.npix_in << a.ck4_shift;
+    const int wstep = a.cib * 256;
+    int xt[TAPS], wt[TAPS];
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) { xt[k] = ((k / KS) * a.TWin + (k % KS)) * a.ldp; wt[k] = k * wstep; }
 
-    for (int c0 = 0; c0 < a.Cin; c0 += a.ck) {
-        if (c0) __syncthreads();
-        // ---- stage the halo tile, channels [c0, c0+ck), zero-filled outside the image / beyond Cin ----
-        // Loads are issued in batches of 8 per thread BEFORE any of them is consumed (out-of-image / beyond-Cin slots
-        // read a zero page instead of branching), so one HBM/L2 latency is paid per batch, not per float4.
-        for (int base = 0; base < total_f4; base += 8 * 256) {
-            f32x4 v[8];
+    // A wave owns CT cout tiles at a time and walks a.cgroups such groups one after the other over the SAME staged input
+    // (cgroups > 1 only when all of Cin is staged at once): narrow register tiles (acc + tot = 8 * CT * PT registers) at high
+    // occupancy, yet the halo tile is fetched once per block for all CT * WC * cgroups cout tiles.
+    for (int cg = 0; cg < a.cgroups; ++cg) {
+        const int ct0 = ((blockIdx.y * WC + wc) * a.cgroups + cg) * CT;
+        // canonical accumulation: `acc` is the fma chain of ONE 16-channel block (all taps), started from +0;
+        // `tot` is the running sum of the block partials in block order
+        f32x4 acc[CT][PT], tot[CT][PT];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * 256 + tid;
-                const int pix = idx >> a.ck4_shift, q = idx & ck4m;
-                const int iy = (int)(((float)pix + 0.5f) * a.inv_TWin);
-                const int ix = pix - iy * a.TWin;
-                const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + 4 * q;
-                const bool inb = idx < total_f4 && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && c < a.cin4;
-                const float* g = inb ? srcb + ((size_t)gy * a.Win + gx) * a.src_cs + c : a.zeros;
-                v[u] = *(const f32x4*)g;
-            }
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * 256 + tid;
-                if (idx < total_f4) {
-                    const int pix = idx >> a.ck4_shift, q = idx & ck4m;
-                    *(f32x4*)(lds + pix * a.ldp + 4 * q) = v[u];
-                }
-            }
+            for (int pt = 0; pt < PT; ++pt) tot[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // cout tiles beyond the last one re-read the last tile's weights (their outputs are discarded by the epilogue):
+        // no branch around the fragment loads, so hipcc keeps a counted s_waitcnt vmcnt(N) and the prefetch stays in flight
+        const float* wbase[CT];
+        // the bias of this lane's 4 couts per cout tile is fetched now (the load's L2 latency hides under the staging) and
+        // not in the epilogue, where it would sit on the block's critical path
+        f32x4 bias4[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+            wbase[ct] = a.wpk + (size_t)ctile * TAPS * a.cib * 256 + lane * 4;
+            bias4[ct] = *(const f32x4*)(a.bias + ctile * 16 + (lane >> 4) * 4);
         }
-        __syncthreads();
-        const int rem = a.Cin - c0;
-        const int nkk = ((rem < a.ck ? rem : a.ck) + 15) >> 4;
-        const int cib0 = c0 >> 4;
-        // K loop over the chunk's 16-channel blocks.  Canonical order of one output: per block ONE fma chain
-        // over (tap kh-major, MFMA step s, k-group g) started from +0 -- the block's first MFMA takes the constant 0 as its
-        // C operand --, then the block partial is added to the running total; blocks in ascending order.
-        // The taps are unrolled at compile time (their LDS / weight offsets are loop-invariant), the only running scalars
-        // are the current and the next block base, and nothing in the loop branches: the accumulators stay in place and
-        // every load is unconditional, so hipcc keeps counted s_waitcnt vmcnt(N) / lgkmcnt(N).  Fragments travel through
-        // register rings: weights (L2, 500+ cycles) RW - 1 steps ahead, pixels (LDS) one step ahead; loads past the
-        // chunk's last block re-read it.
-        constexpr int RX = TAPS > 1 ? 2 : 3;                       // 3x3: two pixel sets; the odd tap count is squared up by one
-                                                                   // register copy per block (below)
-        constexpr int RW = (TAPS > 1 && PT * CT <= 2) ? 9 : 3;     // small wave tiles: a step is only 128-256 MFMA cycles
-        static_assert(TAPS == 1 || TAPS % RW == 0, "weight ring slots must line up across blocks");
-        const int wstep = a.cib * 256;
-        const int klast = nkk - 1;
-        f32x4 wf[RW][CT], xf[RX][PT];
-        auto opaque = [](int v) { asm volatile("" : "+s"(v)); return v; };     // keeps a scalar sum out of LICM's hands
-        auto load_w = [&](f32x4* w, int off) {
+
+        for (int c0 = 0; c0 < a.Cin; c0 += a.ck) {
+            if (cg == 0) {
+                if (c0) __syncthreads();
+                // ---- stage the halo tile, channels [c0, c0+ck), zero-filled outside the image / beyond Cin ----
+                // Loads are issued in batches of 8 per thread BEFORE any of them is consumed (out-of-image / beyond-Cin slots
+                // read a zero page instead of branching), so one HBM/L2 latency is paid per batch, not per float4.
+                for (int base = 0; base < total_f4; base += 8 * 256) {
+                    f32x4 v[8];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(wbase[ct] + off);
-        };
-        auto load_x = [&](f32x4* x, int off) {
+                    for (int u = 0; u < 8; ++u) {
+                        const int idx = base + u * 256 + tid;
+                        const int pix = idx >> a.ck4_shift, q = idx & ck4m;
+                        const int iy = (int)(((float)pix + 0.5f) * a.inv_TWin);
+                        const int ix = pix - iy * a.TWin;
+                        const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + 4 * q;
+                        const bool inb = idx < total_f4 && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && c < a.cin4;
+                        const float* g = inb ? srcb + ((size_t)gy * a.Win + gx) * a.src_cs + c : a.zeros;
+                        v[u] = *(const f32x4*)g;
+                    }
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) x[pt] = *(const f32x4*)__builtin_assume_aligned(lds + xoff[pt] + off, 16);
-        };
-        auto mma = [&](const f32x4* w, const f32x4* x, bool first) {
+                    for (int u = 0; u < 8; ++u) {
+                        const int idx = base + u * 256 + tid;
+                        if (idx < total_f4) {
+                            const int pix = idx >> a.ck4_shift, q = idx & ck4m;
+                            *(f32x4*)(lds + pix * a.ldp + 4 * q) = v[u];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            const int rem = a.Cin - c0;
+            const int nkk = ((rem < a.ck ? rem : a.ck) + 15) >> 4;
+            const int cib0 = c0 >> 4;
+            // K loop over the chunk's 16-channel blocks.  Canonical order of one output: per block ONE fma
+            // chain over (tap kh-major, MFMA step s, k-group g) started from +0 -- the block's first MFMA takes the constant 0
+            // as its C operand --, then the block partial is added to the running total; blocks in ascending order.
+            // The taps are unrolled at compile time (their LDS / weight offsets are loop-invariant), the only running scalars
+            // are the current and the next block base, and nothing in the loop branches: the accumulators stay in place and
+            // every load is unconditional, so hipcc keeps counted s_waitcnt vmcnt(N) / lgkmcnt(N).  Fragments travel through
+            // register rings: weights (L2, 500+ cycles) RW - 1 steps ahead, pixels (LDS) one step ahead; loads past the
+            // chunk's last block re-read it.
+            constexpr int RX = TAPS > 1 ? 2 : 3;                       // 3x3: two pixel sets; the odd tap count is squared up by
+                                                                       // one register copy per block (below)
+            constexpr int RW = (TAPS > 1 && PT * CT <= 2) ? 9 : 3;     // small wave tiles: a step is only 128-256 MFMA cycles
+            static_assert(TAPS == 1 || TAPS % RW == 0, "weight ring slots must line up across blocks");
+            const int klast = nkk - 1;
+            f32x4 wf[RW][CT], xf[RX][PT];
+            auto opaque = [](int v) { asm volatile("" : "+s"(v)); return v; };     // keeps a scalar sum out of LICM's hands
+            auto load_w = [&](f32x4* w, int off) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(wbase[ct] + off);
+            };
+            auto load_x = [&](f32x4* x, int off) {
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) x[pt] = *(const f32x4*)__builtin_assume_aligned(lds + xoff[pt] + off, 16);
+            };
+            auto mma = [&](const f32x4* w, const f32x4* x, bool first) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt)
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][s], x[pt][s],
+                                                                               (first && s == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[ct][pt], 0, 0, 0);
+            };
+            auto bank = [&]() {                                      // end of a block: its partial joins the total
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                    for (int pt = 0; pt < PT; ++pt)
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][s], x[pt][s],
-                                                                           (first && s == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[ct][pt], 0, 0, 0);
-        };
-        auto bank = [&]() {                                      // end of a block: its partial joins the total
+                    for (int pt = 0; pt < PT; ++pt) tot[ct][pt] += acc[ct][pt];
+            };
+            if constexpr (TAPS > 1) {
+                // prologue: weight steps 0 .. RW-2 and pixel step 0 of the first block (a block has TAPS >= RW - 1 steps)
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+                for (int k = 0; k < RW - 1; ++k) load_w(wf[k], cib0 * 256 + wt[k]);
+                load_x(xf[0], xt[0]);
+                for (int kb = 0; kb < nkk; ++kb) {
+                    const int kn = kb < klast ? kb + 1 : klast;
+                    const int wk = opaque((cib0 + kb) * 256), wkn = opaque((cib0 + kn) * 256);
+                    const int xk = opaque(kb * 16), xkn = opaque(kn * 16);
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) tot[ct][pt] += acc[ct][pt];
-        };
-        if constexpr (TAPS > 1) {
-            int xt[TAPS], wt[TAPS];
-#pragma unroll
-            for (int t = 0; t < TAPS; ++t) { xt[t] = ((t / KS) * a.TWin + (t % KS)) * a.ldp; wt[t] = t * wstep; }
-            // prologue: weight steps 0 .. RW-2 and pixel step 0 of the first block (a block has TAPS >= RW - 1 steps)
-#pragma unroll
-            for (int t = 0; t < RW - 1; ++t) load_w(wf[t], cib0 * 256 + wt[t]);
-            load_x(xf[0], xt[0]);
-            for (int kb = 0; kb < nkk; ++kb) {
-                const int kn = kb < klast ? kb + 1 : klast;
-                const int wk = opaque((cib0 + kb) * 256), wkn = opaque((cib0 + kn) * 256);
-                const int xk = opaque(kb * 16), xkn = opaque(kn * 16);
-#pragma unroll
-                for (int t = 0; t < TAPS; ++t) {
-                    constexpr int AW = RW - 1;
-                    load_w(wf[(t + AW) % RW], opaque(((t + AW) >= TAPS ? wkn : wk) + wt[(t + AW) % TAPS]));
-                    load_x(xf[(t + 1) % RX], opaque(((t + 1) >= TAPS ? xkn : xk) + xt[(t + 1) % TAPS]));
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma(wf[t % RW], xf[t % RX], t == 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                bank();
-                if constexpr (TAPS % RX != 0) {                  // the next block's tap 0 landed in slot TAPS % RX: move it to slot 0
-#pragma unroll
-                    for (int pt = 0; pt < PT; ++pt) xf[0][pt] = xf[TAPS % RX][pt];
-                }
-            }
-        } else {
-            // pointwise: a step is a block; RX blocks per trip so that the ring slots are compile-time
-            auto koff = [&](int kb) { return kb < klast ? kb : klast; };
-            load_w(wf[0], (cib0 + koff(0)) * 256);
-            load_w(wf[1], (cib0 + koff(1)) * 256);
-            load_x(xf[0], 0);
-            int kb0 = 0;
-            for (; kb0 + RX <= nkk; kb0 += RX) {              // whole trips: no guard, no branch inside
-#pragma unroll
-                for (int t = 0; t < RX; ++t) {
-                    load_w(wf[(t + 2) % RW], opaque((cib0 + koff(kb0 + t + 2)) * 256));
-                    load_x(xf[(t + 1) % RX], opaque(koff(kb0 + t + 1) * 16));
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma(wf[t % RW], xf[t % RX], true);
+                    for (int k = 0; k < TAPS; ++k) {
+                        constexpr int AW = RW - 1;
+                        load_w(wf[(k + AW) % RW], opaque(((k + AW) >= TAPS ? wkn : wk) + wt[(k + AW) % TAPS]));
+                        load_x(xf[(k + 1) % RX], opaque(((k + 1) >= TAPS ? xkn : xk) + xt[(k + 1) % TAPS]));
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma(wf[k % RW], xf[k % RX], k == 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     bank();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if (kb0 < nkk) {                                  // ragged tail trip
+                    if constexpr (TAPS % RX != 0) {                  // the next block's tap 0 landed in slot TAPS % RX: move it to slot 0
 #pragma unroll
-                for (int t = 0; t < RX; ++t) {
-                    load_w(wf[(t + 2) % RW], opaque((cib0 + koff(kb0 + t + 2)) * 256));
-                    load_x(xf[(t + 1) % RX], opaque(koff(kb0 + t + 1) * 16));
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (kb0 + t < nkk) { mma(wf[t % RW], xf[t % RX], true); bank(); }
-                    __builtin_amdgcn_sched_barrier(0);
+                        for (int pt = 0; pt < PT; ++pt) xf[0][pt] = xf[TAPS % RX][pt];
+                    }
+                }
+            } else {
+                // pointwise: a step is a block; RX blocks per trip so that the ring slots are compile-time
+                auto koff = [&](int kb) { return kb < klast ? kb : klast; };
+                load_w(wf[0], (cib0 + koff(0)) * 256);
+                load_w(wf[1], (cib0 + koff(1)) * 256);
+                load_x(xf[0], 0);
+                int kb0 = 0;
+                for (; kb0 + RX <= nkk; kb0 += RX) {              // whole trips: no guard, no branch inside
+#pragma unroll
+                    for (int k = 0; k < RX; ++k) {
+                        load_w(wf[(k + 2) % RW], opaque((cib0 + koff(kb0 + k + 2)) * 256));
+                        load_x(xf[(k + 1) % RX], opaque(koff(kb0 + k + 1) * 16));
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma(wf[k % RW], xf[k % RX], true);
+                        bank();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (kb0 < nkk) {                                  // ragged tail trip
+#pragma unroll
+                    for (int k = 0; k < RX; ++k) {
+                        load_w(wf[(k + 2) % RW], opaque((cib0 + koff(kb0 + k + 2)) * 256));
+                        load_x(xf[(k + 1) % RX], opaque(koff(kb0 + k + 1) * 16));
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (kb0 + k < nkk) { mma(wf[k % RW], xf[k % RX], true); bank(); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         }
-    }
 
-    conv_epilogue<STRIDE, PT, CT, WP>(a, tot, bias4, lane, wp, ct0, b, oy0, ox0, npix);
+        if constexpr (!F2) {
+            conv_epilogue<STRIDE, PT, CT, WP>(a, tot, bias4, lane, wp, ct0, b, oy0, ox0, npix);
+        } else {
+            // first conv's output (bias + activation applied: the value the unfused launch would have stored) -> LDS image
+            // [pixel][channel] with pixel stride ldp2, behind the halo tile; padded cout tiles (all-zero weights and bias)
+            // give exact zeros, which is what the second conv's padded k-blocks expect
+            float* y1 = lds + a.lds_buf_floats;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    if (ct0 + ct >= a.n_ctiles) continue;
+                    f32x4 v = tot[ct][pt] + bias4[ct];
+                    if (a.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                    *(f32x4*)(y1 + ((wp * PT + pt) * 16 + (lane & 15)) * a.ldp2 + (ct0 + ct) * 16 + (lane >> 4) * 4) = v;
+                }
+        }
+    }
+    if constexpr (F2) {
+        __syncthreads();
+        // ---- second stage: the 1x1 conv over the LDS image; wave (wp, wc) keeps its pixel tiles and takes cout tiles
+        // wc, wc + WC, ... of the second conv.  Canonical order as everywhere: per 16-channel block a chain from +0.
+        const float* y1 = lds + a.lds_buf_floats;
+        int x2off[PT]; size_t po[PT]; bool ok[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int p = (wp * PT + pt) * 16 + (lane & 15);
+            x2off[pt] = p * a.ldp2 + (lane >> 4) * 4;
+            const int pp = p < npix ? p : 0;
+            const int ly = (int)(((float)pp + 0.5f) * a.inv_TW);
+            const int lx = pp - ly * a.TW;
+            const int oy = oy0 + ly, ox = ox0 + lx;
+            ok[pt] = (p < npix) && (oy < a.Hout) && (ox < a.Wout);
+            po[pt] = ((size_t)b * a.Hout + oy) * a.Wout + ox;
+        }
+        for (int ct2 = wc; ct2 < a.n_ctiles2; ct2 += WC) {
+            const float* wb = a.w2 + (size_t)ct2 * a.cib2 * 256 + lane * 4;
+            f32x4 tot2[PT];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) tot2[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 w_cur = *(const f32x4*)wb;
+            for (int cb = 0; cb < a.cib2; ++cb) {
+                const int cn = cb + 1 < a.cib2 ? cb + 1 : cb;
+                const f32x4 w_nxt = *(const f32x4*)(wb + cn * 256);
+                f32x4 x2[PT], p2[PT];
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) x2[pt] = *(const f32x4*)__builtin_assume_aligned(y1 + x2off[pt] + cb * 16, 16);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt)
+                        p2[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_cur[s], x2[pt][s], s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : p2[pt], 0, 0, 0);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) tot2[pt] += p2[pt];
+                w_cur = w_nxt;
+            }
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+                store_tile(tot2[pt], a.bias2, a.act2, nullptr, 0, a.dst2, a.dst2_cs, a.Cout2, ct2, lane, po[pt], ok[pt]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- v6 (3x3, split K)

@@ -18,6 +18,9 @@ KernelFn pick_f32_stream(int CT, int PT);     // conv_f32_k1.hip
 // small pixel tiles for latency-bound launches (ck <= 64); CT in {1, 2, 4}, WP in {1, 2, 4}
 KernelFn pick_f32_pipe(int CT, int WP, bool single, int ck, int PT);   // conv_f32_pipe.hip
 
+// conv_igemm_f32<3, STRIDE, PT, CT, WP, F2 = true> (a pointwise conv fused behind the 3x3): same (PT, CT, WP) space as above
+KernelFn pick_f32_fused_s1(int CT, int WP, int PT);     // conv_f32_fused_s1.hip
+KernelFn pick_f32_fused_s2(int CT, int WP, int PT);     // conv_f32_fused_s2.hip
 // conv_splitk_f32<3, STRIDE, PT, CT>: PT, CT in {1, 2}
 KernelFn pick_f32_splitk(int stride, int CT, int PT);   // conv_f32_splitk.hip
 

@@ -30,7 +30,8 @@ void pack_conv_weights(const float* w, int cout, int cin, int k, float* out) {
 
 namespace {
 
-struct Plan { int CT, WP, TW, TH, ck; size_t lds; double cost; int version; int buf_floats; int PT; };   // PT 0 = default (4, or 3 with CT 5)
+struct Plan { int CT, WP, TW, TH, ck; size_t lds; double cost; int version; int buf_floats; int PT; int G = 1; bool f2 = false; };
+// PT 0 = default (4, or 3 with CT 5); G = groups of CT cout tiles a wave walks over one staged input; f2 = fused pointwise stage
 
 KernelFn pick_kernel(int ks, int stride, int CT, int WP, int PT) {
     if (ks == 1 && stride == 1) return pick_f32_k1(CT, WP, PT);
@@ -66,7 +67,8 @@ double latency_factor(const Shape& sh, long blocks, int PT, int CT, int split = 
 
 // Candidate launch plans for one conv: for every wave arrangement (CT, WC) the best output tile, with every
 // feasible staged-channel count.  Sorted by a static cost model; the engine may time the first few (autotune).
-std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int cin, int ks, int stride, bool have_zero_page, bool half) {
+std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int cin, int ks, int stride, bool have_zero_page, bool half,
+                                  int f2_cin16 = 0) {
     static const int max_ct = env_int("MI355_MAX_CT", 5);          // tuning knobs (experiments only)
     static const int min_wc = env_int("MI355_MIN_WC", 1);
     static const int small_pt = env_int("MI355_SMALL_PT", 1);      // 0: never offer the 1- / 2-pixel-tile wave shapes
@@ -90,32 +92,45 @@ std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int ci
             if (PTsel == 8 && CT > 4) continue;
             if (!half && PTsel != 0 && CT > 2) continue;               // small wave tiles exist for CT 1 and 2
             const int WP = 4 / WC, PT = PTsel ? PTsel : (CT == 5 ? 3 : 4), P = WP * PT * 16;
-            const int cover = CT * WC, nblk = (n_ctiles + cover - 1) / cover;
+            // cout groups: G = 1 (one group; more cout tiles = more blocks along grid.y, each staging the input again) or, when
+            // all of Cin is staged at once, G = as many groups as cover every cout tile from ONE staged input (fp32 kernels)
+            const int g_full = (n_ctiles + CT * WC - 1) / (CT * WC);
+            for (int G : (half || g_full < 2 || g_full > 8) ? std::vector<int>{1} : std::vector<int>{1, g_full}) {
+            const int cover = CT * WC * G, nblk = (n_ctiles + cover - 1) / cover;
             if (cover >= 2 * n_ctiles && cover > CT) continue;          // more than half of the cout tiles would be padding
+            if (f2_cin16 && nblk != 1) continue;                        // a fused pointwise stage needs ALL first-conv channels in the block
             const double waste_c = (double)nblk * cover / n_ctiles;
             // staged channels per chunk, in 4-byte units; the fp16 kernels (2 channels per unit) also get 128: their K loop
             // is so short that the two barriers + pipeline refill per chunk show, above all in the 1x1 layers
             for (int ck = half ? 128 : 64; ck >= 16; ck >>= 1) {
                 if (ck > cin16 && ck != 16) continue;
+                if (G > 1 && ck < cin16) continue;                      // groups re-run the K loop over ONE staged chunk
                 Plan best{}; best.cost = 1e30;
                 for (int TW = 1; TW <= P && TW <= W; ++TW) {
                     int TH = P / TW; if (TH > H) TH = H;
                     if (TH < 1) continue;
                     const long tiles = (long)((W + TW - 1) / TW) * ((H + TH - 1) / TH);
                     const int THin = (TH - 1) * stride + ks, TWin = (TW - 1) * stride + ks;
-                    const size_t lds = (size_t)THin * TWin * (ck + 4) * 4;
+                    const int stage_floats = round_up(THin * TWin * (ck + 4), 4);
+                    // fused pointwise stage: the first conv's output image [P pixels][f2_cin16 + 4] lives behind the halo tile
+                    const size_t lds = (size_t)stage_floats * 4 + (f2_cin16 ? (size_t)P * (f2_cin16 + 4) * 4 : 0);
                     if (lds > LDS_HARD) continue;
                     const double infl = waste_c * (double)tiles * P / ((double)W * H);
                     const double halo = (double)THin * TWin / ((double)TH * TW * stride * stride);
                     const int stages = (cin16 + ck - 1) / ck;
                     double cost = infl * (1.0 + 0.03 * halo * nblk) * (1.0 + 0.04 * (stages - 1)) * (1.0 + 0.04 * (CT - 1))
                                   + (lds > LDS_SOFT ? 0.15 : 0.0);
-                    if (latency_bound) cost *= latency_factor(sh, tiles * images * nblk, PT, CT);
-                    if (cost < best.cost) best = Plan{CT, WP, TW, TH, ck, lds, cost, 1, 0, PTsel};
+                    if (latency_bound) cost *= latency_factor(sh, tiles * images * nblk, PT, CT * G);
+                    if (cost < best.cost) { best = Plan{CT, WP, TW, TH, ck, lds, cost, 1, f2_cin16 ? stage_floats : 0, PTsel}; best.G = G; best.f2 = f2_cin16 != 0; }
                 }
                 if (best.cost < 1e30) out.push_back(best);
             }
+            }
         }
+    if (f2_cin16) {                       // only the LDS-staged kernel has the fused form
+        std::sort(out.begin(), out.end(), [](const Plan& a, const Plan& b) { return a.cost < b.cost; });
+        return out;
+    }
     if (ks == 3 && latency_bound && cin16 >= 64) {
         // v6: the four waves of a block split the 16-channel blocks of the SAME PT x CT tiles (bit-exact: the canonical order
         // sums block partials); LDS = halo tile of one chunk + cib x CT x PT partial tiles of 1 KiB
@@ -236,9 +251,16 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
                                          : (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.version == 3 ? p.buf_floats : p.PT))
                        : (p.version == 3 ? pick_f32_stream(p.CT, p.buf_floats)
                           : p.version == 4 ? pick_f32_pipe(p.CT, p.WP, c.Cin <= p.ck, p.ck, p.PT)
-                          : p.version == 6 ? pick_f32_splitk(c.stride, p.CT, p.PT) : pick_kernel(c.k, c.stride, p.CT, p.WP, p.PT));
+                          : p.version == 6 ? pick_f32_splitk(c.stride, p.CT, p.PT)
+                          : p.f2 ? (c.stride == 1 ? pick_f32_fused_s1(p.CT, p.WP, p.PT) : pick_f32_fused_s2(p.CT, p.WP, p.PT))
+                          : pick_kernel(c.k, c.stride, p.CT, p.WP, p.PT));
     if (!fn) return "conv: no kernel instance";
     a.zeros = c.zeros; a.lds_buf_floats = p.buf_floats;
+    a.cgroups = std::max(1, p.G);
+    if (p.f2) {
+        a.w2 = c.f2_wpk; a.bias2 = c.f2_bias; a.dst2 = c.f2_dst; a.dst2_cs = c.f2_dst_cs; a.Cout2 = c.f2_cout; a.act2 = c.f2_act;
+        a.n_ctiles2 = (c.f2_cout + 15) / 16; a.cib2 = (c.Cout + 15) / 16; a.ldp2 = round_up(c.Cout, 16) + 4;
+    }
     if (half && p.version == 4) a.lds_buf_floats = 0;
     if (half && p.version == 1) { static const int ex = env_int("MI355_F16_EXP", 0); a.lds_buf_floats = ex; }
     a.TW = p.TW; a.TH = p.TH;
@@ -267,7 +289,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
         }
         out->grid_x = std::min(out->grid_x, (unsigned)std::max(1, 256 * per_cu / gy));
     }
-    out->grid_y = (unsigned)((a.n_ctiles + p.CT * WC - 1) / (p.CT * WC));
+    out->grid_y = (unsigned)((a.n_ctiles + p.CT * WC * a.cgroups - 1) / (p.CT * WC * a.cgroups));
     out->lds = p.lds;
     out->a = a;
     out->CT = p.CT; out->WP = p.WP; out->version = p.version;
@@ -279,7 +301,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
         out->lds = 0;
         out->a.tiles_x = (int)out->grid_x;
     }
-    out->flops = 2.0 * c.B * c.Hout * c.Wout * (double)c.Cout * c.Cin * c.k * c.k;
+    out->flops = 2.0 * c.B * c.Hout * c.Wout * (double)c.Cout * (c.Cin * c.k * c.k + (p.f2 ? c.f2_cout : 0));
     return nullptr;
 }
 
@@ -289,8 +311,10 @@ const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out
     const int H = c.k == 1 ? 1 : c.Hout, W = c.k == 1 ? c.B * c.Hout * c.Wout : c.Wout;
     const bool half = c.dtype == 1;
     // H x W = the map one block grid walks: the image for 3x3 convs (`images` of them), batch x space flattened for 1x1
+    if (c.f2_cout && (half || c.k != 3 || c.res || !c.f2_wpk || !c.f2_bias || !c.f2_dst || (c.f2_dst_cs & 3) || ((uintptr_t)c.f2_dst & 15)))
+        return "conv: a fused pointwise stage needs an fp32 3x3 conv without residual and aligned second-stage buffers";
     const std::vector<Plan> plans = enumerate_plans(H, W, c.k == 1 ? 1 : c.B, (c.Cout + 15) / 16, half ? (c.Cin + 1) / 2 : c.Cin, c.k,
-                                                    c.stride, c.zeros != nullptr, half);
+                                                    c.stride, c.zeros != nullptr, half, c.f2_cout ? round_up(c.Cout, 16) : 0);
     if (plans.empty()) return "conv: no launch plan fits in LDS";
     for (const Plan& p : plans) {
         if (c.src2 && p.version != 4) continue;       // upsample-on-read exists in the v4 kernels only

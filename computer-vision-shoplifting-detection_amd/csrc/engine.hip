@@ -139,6 +139,11 @@ struct mi355_yolo {
     // output only conv op j reads (or -1); fused_away[i] = that upsample is not launched.  Decided when the weights are
     // loaded (program structure) and confirmed per shape (a v4 launch plan must exist), MI355_FUSE_UPSAMPLE=0 disables it.
     std::vector<int> fuse_up; std::vector<char> fused_away;
+    // Conv3x3 -> Conv1x1 fused into one launch (fp32): fuse2[i] = index of the pointwise conv op whose ONLY input is conv op
+    // i's output slice, which nobody else reads (or -1): the stride-2 convs in front of every C2f / C3 and the last two convs
+    // of every head branch.  Decided from the program at load time, confirmed per shape (a fused launch plan must exist);
+    // skip_op[j] = the pointwise op j runs inside its producer's launch.  MI355_FUSE_1X1=0 disables it.
+    std::vector<int> fuse2; std::vector<char> skip_op;
     // Small chunks leave most of the chip idle inside one conv launch, but the graph has independent branches (the box / class /
     // keypoint chains of the three head levels run beside the rest of the neck): ops are dealt to a few HIP streams along the
     // program's dependency DAG (RAW on buffer slices), in depth order, a chain inheriting its producer's stream; an op waits
@@ -329,6 +334,30 @@ static int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
             h->fuse_up[reader] = (int)i; h->fused_away[i] = 1;
         }
     }
+    h->fuse2.assign(h->ops.size(), -1); h->skip_op.assign(h->ops.size(), 0);
+    const char* f2env = getenv("MI355_FUSE_1X1");
+    if (!h->half && (!f2env || atoi(f2env) != 0)) {
+        for (size_t i = 0; i < h->ops.size(); ++i) {
+            const FileOp& p3 = h->ops[i];
+            if (p3.type != OP_CONV || h->convs[p3.conv].k != 3 || p3.res_buf >= 0) continue;
+            bool is_head = false;
+            for (const FileLevel& lv : h->levels) is_head |= ((int)lv.buf == p3.dst_buf);
+            if (is_head) continue;
+            int reader = -1, n_readers = 0;
+            for (size_t j = 0; j < h->ops.size(); ++j) {
+                const FileOp& o = h->ops[j];
+                if (j == i || o.type == OP_STEM) continue;
+                const bool reads = o.src_buf == p3.dst_buf && o.src_choff < p3.dst_choff + p3.dst_c && p3.dst_choff < o.src_choff + o.src_c;
+                const bool reads_res = o.res_buf == p3.dst_buf && o.res_choff < p3.dst_choff + p3.dst_c && p3.dst_choff < o.res_choff + o.dst_c;
+                if (reads || reads_res) { ++n_readers; reader = reads && !reads_res ? (int)j : -2; }
+            }
+            if (n_readers != 1 || reader <= (int)i) continue;
+            const FileOp& p1 = h->ops[reader];
+            if (p1.type != OP_CONV || h->convs[p1.conv].k != 1 || h->convs[p1.conv].s != 1 || p1.res_buf >= 0) continue;
+            if (p1.src_choff != p3.dst_choff || p1.src_c != p3.dst_c || h->fuse_up[reader] >= 0) continue;   // reads exactly that slice
+            h->fuse2[i] = reader;
+        }
+    }
     float lut[256];
     for (int i = 0; i < 256; ++i) lut[i] = (float)i / 255.0f;     // im /= 255 (IEEE fp32 division)
     HIPCHK(hipMalloc(&h->lut, sizeof(lut)));
@@ -404,7 +433,7 @@ static int build_schedule(mi355_yolo* h) {
 // process) need not repeat it.  The autotuner's CHOICES -- an index into each conv's candidate list -- are kept in a small
 // text file keyed by (model image hash, precision, frames, H, W, planner version); a file whose candidate counts do not
 // match the running planner is ignored.  MI355_PLAN_CACHE=<dir> moves the directory, MI355_PLAN_CACHE=0 turns it off.
-static const char* kPlanVersion = "mi355-plans-r02c";
+static const char* kPlanVersion = "mi355-plans-r02d";
 
 static std::string plan_cache_path(const mi355_yolo* h, int nb, int Hl, int Wl) {
     const char* e = getenv("MI355_PLAN_CACHE");
@@ -431,7 +460,8 @@ static bool load_plan_choices(const mi355_yolo* h, int nb, int Hl, int Wl, const
     std::vector<int> got(n_cands.size(), 0);
     for (size_t i = 0; ok && i < n_cands.size(); ++i) {
         int c = 0, nc = 0;
-        ok = std::fscanf(f, "%d/%d", &c, &nc) == 2 && nc == n_cands[i] && c >= 0 && (c < nc || nc == 0);
+        // c >= 0: index into the plain list (nc % 1000 entries); c < 0: fused plan -(c + 1) of nc / 1000
+        ok = std::fscanf(f, "%d/%d", &c, &nc) == 2 && nc == n_cands[i] && (c >= 0 ? (c < nc % 1000 || nc == 0) : (-c - 1 < nc / 1000));
         got[i] = c;
     }
     std::fclose(f);
@@ -487,10 +517,12 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
     h->plans.assign(h->ops.size(), ConvLaunch{});
     const bool tune_log = getenv("MI355_TUNE_LOG") != nullptr;
     const std::array<int, 3> shape_key{nb, Hl, Wl};
-    // pass 1: the candidate lists (host work only)
-    std::vector<std::vector<ConvLaunch>> cands(h->ops.size());
-    std::vector<ConvArgs> cargs(h->ops.size());
+    // pass 1: the candidate lists (host work only).  A 3x3 conv that may absorb its pointwise consumer (fuse2) gets two lists:
+    // the plain one and the fused one; which form runs is decided below, by the stopwatch.
+    std::fill(h->skip_op.begin(), h->skip_op.end(), 0);
+    std::vector<std::vector<ConvLaunch>> cands(h->ops.size()), cands_f(h->ops.size());
     std::vector<int> n_cands(h->ops.size(), 0);
+    const size_t top = (size_t)std::max(1, h->autotune);
     for (size_t i = 0; i < h->ops.size(); ++i) {
         const FileOp& o = h->ops[i];
         if (o.type != OP_CONV) continue;
@@ -524,53 +556,83 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                 h->fused_away[h->fuse_up[i]] = 0;
             }
         }
+        if (h->fuse2[i] >= 0) {
+            const FileOp& o1 = h->ops[h->fuse2[i]];
+            const FileConv& c1 = h->convs[o1.conv];
+            ConvArgs f = a;
+            f.f2_wpk = h->dconv[o1.conv].wpk; f.f2_bias = h->dconv[o1.conv].bias;
+            f.f2_dst = h->view(o1.dst_buf, o1.dst_choff); f.f2_dst_cs = h->dbuf_cs[o1.dst_buf]; f.f2_cout = c1.cout; f.f2_act = c1.act;
+            if (plan_conv_candidates(f, &cands_f[i]) != nullptr) cands_f[i].clear();
+            if (cands_f[i].size() > top) cands_f[i].resize(top);
+        }
         if (cands[i].empty()) KCHK(plan_conv_candidates(a, &cands[i]));
-        cargs[i] = a;
-        n_cands[i] = (int)std::min<size_t>(cands[i].size(), (size_t)std::max(1, h->autotune));
+        if (cands[i].size() > top) cands[i].resize(top);
+        n_cands[i] = (int)cands[i].size() + 1000 * (int)cands_f[i].size();
         h->plans[i] = cands[i][0];
     }
-    // pass 2: choices -- this process's memory, then the plan file, then the stopwatch
+    // pass 2: choices -- this process's memory, then the plan file, then the stopwatch.  chosen[i] >= 0: index into the plain
+    // list; chosen[i] = -(k + 1): fused plan k (the pointwise consumer then runs inside this launch and is skipped).
     std::vector<int> chosen(h->ops.size(), 0);
     bool have = false;
     for (const auto& t : h->tuned) if (t.first == shape_key) { chosen = t.second; have = true; }
     if (!have && h->autotune) have = load_plan_choices(h, nb, Hl, Wl, n_cands, &chosen);
-    if (have) {
-        for (size_t i = 0; i < h->ops.size(); ++i)
-            if (h->ops[i].type == OP_CONV && (size_t)chosen[i] < cands[i].size()) h->plans[i] = cands[i][chosen[i]];
-    } else if (h->autotune) {
-        for (size_t i = 0; i < h->ops.size(); ++i) {
-            const FileOp& o = h->ops[i];
-            if (o.type != OP_CONV || cands[i].size() < 2) continue;
-            const FileConv& c = h->convs[o.conv];
-            const ConvArgs& a = cargs[i];
-            // Time the most promising launch plans on the real buffers (outputs are overwritten by the next real
-            // pass; the accumulation order is plan-independent, so the choice cannot change results).
-            float best_ms = 1e30f;
-            for (int k = 0; k < n_cands[i]; ++k) {
-                float ms = 1e30f;
-                for (int rep = 0; rep < 3; ++rep) {
-                    HIPCHK(hipEventRecord(h->ev0, h->stream));
-                    KCHK(run_conv(cands[i][k], h->stream));
-                    HIPCHK(hipEventRecord(h->ev1, h->stream));
-                    HIPCHK(hipEventSynchronize(h->ev1));
-                    float t = 0.f;
-                    HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
-                    if (rep > 0) ms = std::min(ms, t);          // first run warms the instruction cache
-                }
-                if (ms < best_ms) { best_ms = ms; h->plans[i] = cands[i][k]; chosen[i] = k; }
-                if (tune_log)
-                    fprintf(stderr, "[tune] %-22s %4u->%-4u k%u s%u @%dx%d  v%d CT%d PT%d WP%d tile %dx%d ck%d lds %zu grid %ux%u : %.1f us  %.1f TFLOP/s\n",
-                            c.name, c.cin, c.cout, c.k, c.s, a.Hout, a.Wout, cands[i][k].version, cands[i][k].CT, cands[i][k].PT, cands[i][k].WP, cands[i][k].a.TW,
-                            cands[i][k].a.TH, cands[i][k].a.ck, cands[i][k].lds, cands[i][k].grid_x, cands[i][k].grid_y, ms * 1e3,
-                            cands[i][k].flops / (ms * 1e-3) / 1e12);
+    auto time_list = [&](const std::vector<ConvLaunch>& list, const char* name, int* best_k, float* best_ms) -> int {
+        // Time launch plans on the real buffers (outputs are overwritten by the next real pass; the accumulation order is
+        // plan-independent, so the choice cannot change results).
+        *best_ms = 1e30f; *best_k = 0;
+        for (size_t k = 0; k < list.size(); ++k) {
+            float ms = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                HIPCHK(hipEventRecord(h->ev0, h->stream));
+                KCHK(run_conv(list[k], h->stream));
+                HIPCHK(hipEventRecord(h->ev1, h->stream));
+                HIPCHK(hipEventSynchronize(h->ev1));
+                float t = 0.f;
+                HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
+                if (rep > 0) ms = std::min(ms, t);          // first run warms the instruction cache
             }
-            if (tune_log) fprintf(stderr, "[tune] -> v%d CT%d PT%d WP%d tile %dx%d ck%d : %.1f us\n", h->plans[i].version, h->plans[i].CT,
-                                  h->plans[i].PT, h->plans[i].WP, h->plans[i].a.TW, h->plans[i].a.TH, h->plans[i].a.ck, best_ms * 1e3);
+            if (ms < *best_ms) { *best_ms = ms; *best_k = (int)k; }
+            if (tune_log)
+                fprintf(stderr, "[tune] %-40s v%d CT%d PT%d WP%d G%d%s tile %dx%d ck%d lds %zu grid %ux%u : %.1f us  %.1f TFLOP/s\n",
+                        name, list[k].version, list[k].CT, list[k].PT, list[k].WP, list[k].a.cgroups, list[k].a.w2 ? " +1x1" : "", list[k].a.TW,
+                        list[k].a.TH, list[k].a.ck, list[k].lds, list[k].grid_x, list[k].grid_y, ms * 1e3, list[k].flops / (ms * 1e-3) / 1e12);
+        }
+        return MI355_OK;
+    };
+    if (!have && h->autotune) {
+        std::vector<char> done(h->ops.size(), 0);
+        for (size_t i = 0; i < h->ops.size(); ++i) {
+            if (h->ops[i].type != OP_CONV || done[i]) continue;
+            const char* name = h->convs[h->ops[i].conv].name;
+            int k = 0; float ms = 0.f;
+            if (cands[i].size() > 1 || !cands_f[i].empty()) { const int rc = time_list(cands[i], name, &k, &ms); if (rc) return rc; }
+            chosen[i] = k;
+            if (!cands_f[i].empty()) {
+                // fused vs separate: best fused launch against best 3x3 + best pointwise launch
+                const int j = h->fuse2[i];
+                int kf = 0, kj = 0; float msf = 0.f, msj = 0.f;
+                int rc = time_list(cands_f[i], name, &kf, &msf); if (rc) return rc;
+                rc = time_list(cands[j], h->convs[h->ops[j].conv].name, &kj, &msj); if (rc) return rc;
+                chosen[j] = kj; done[j] = 1;
+                if (msf < ms + msj) chosen[i] = -(kf + 1);
+                if (tune_log) fprintf(stderr, "[tune] %s: fused %.1f us vs separate %.1f + %.1f us -> %s\n", name, msf * 1e3, ms * 1e3, msj * 1e3,
+                                      chosen[i] < 0 ? "fused" : "separate");
+            }
         }
         h->tuned.push_back({shape_key, chosen});
         save_plan_choices(h, nb, Hl, Wl, n_cands, chosen);
+        have = true;
     }
     if (have) {
+        for (size_t i = 0; i < h->ops.size(); ++i) {
+            if (h->ops[i].type != OP_CONV) continue;
+            if (chosen[i] < 0 && (size_t)(-chosen[i] - 1) < cands_f[i].size()) {
+                h->plans[i] = cands_f[i][-chosen[i] - 1];
+                h->skip_op[h->fuse2[i]] = 1;
+            } else if (chosen[i] >= 0 && (size_t)chosen[i] < cands[i].size()) {
+                h->plans[i] = cands[i][chosen[i]];
+            }
+        }
         bool known = false;
         for (const auto& t : h->tuned) known |= (t.first == shape_key);
         if (!known) h->tuned.push_back({shape_key, chosen});
@@ -579,7 +641,7 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
     if (getenv("MI355_SCHED_LOG")) {      // launch order of a pass for tools/layer_report.py: position, op index, stream, launched
         for (size_t pos = 0; pos < h->sched_order.size(); ++pos) {
             const int idx = h->sched_order[pos];
-            fprintf(stderr, "[sched] %zu %d %d %d\n", pos, idx, h->op_stream[idx], !(h->ops[idx].type == OP_UPSAMPLE && h->fused_away[idx]));
+            fprintf(stderr, "[sched] %zu %d %d %d\n", pos, idx, h->op_stream[idx], !(h->ops[idx].type == OP_UPSAMPLE && h->fused_away[idx]) && !h->skip_op[idx]);
         }
     }
     return MI355_OK;
@@ -660,6 +722,7 @@ static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, c
             KCHK(launch_stem(s, st));
             pf.end();
         } else if (o.type == OP_CONV) {
+            if (h->skip_op[i]) return MI355_OK;         // a pointwise conv that runs inside its producer's launch
             ConvLaunch l = h->plans[i];
             if (nb != h->cur_nb) {             // tail chunk: same buffers, fewer frames
                 if (h->convs[o.conv].k == 1 && l.version == 3) {
@@ -728,7 +791,10 @@ static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, c
                 HIPCHK(hipStreamWaitEvent(st, h->op_done[dep], 0));
             }
             const int rc = launch_op((size_t)idx, st); if (rc) return rc;
+            if (h->skip_op[idx]) continue;              // its event was recorded behind the producer's (fused) launch
             if (h->op_signals[idx] && !(h->ops[idx].type == OP_UPSAMPLE && h->fused_away[idx])) HIPCHK(hipEventRecord(h->op_done[idx], st));
+            if (h->fuse2[idx] >= 0 && h->skip_op[h->fuse2[idx]] && h->op_signals[h->fuse2[idx]])
+                HIPCHK(hipEventRecord(h->op_done[h->fuse2[idx]], st));
         }
         for (int l : h->leaf_ops)
             if (h->op_stream[l] != 0) HIPCHK(hipStreamWaitEvent(h->stream, h->op_done[l], 0));
