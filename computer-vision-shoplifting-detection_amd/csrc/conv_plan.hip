@@ -77,8 +77,9 @@ std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int ci
     const Shape sh{H, W, n_ctiles, cin16, ks, stride};
     // Is the default wave tile (4 pixel tiles) latency-bound on this shape?  Only then are the small wave tiles offered: at
     // large batches they would only crowd the autotuner's candidate list.
-    const bool latency_bound = !half && small_pt &&
-                               latency_factor(sh, ((long)W * H + 63) / 64 * images * ((n_ctiles + 3) / 4), 4, 1) > 1.0;
+    // ... or leaves the chip thin: fewer than ~6 waves per SIMD in all, where shorter waves also hide each other's latencies better.
+    const long blocks_default = ((long)W * H + 63) / 64 * images * ((n_ctiles + 3) / 4);
+    const bool latency_bound = !half && small_pt && (latency_factor(sh, blocks_default, 4, 1) > 1.0 || blocks_default < 1536);
     // Pixel tiles per wave.  fp16: wave tiles of 8 pixel tiles (128 pixels x CT*16 couts) halve the weight bytes fetched per
     // MFMA -- the f16 MFMA retires a 1-KiB fragment pair in 16 cycles, so those kernels are bound by L1/L2 fragment traffic.
     // fp32: 0 = the default (4, or 3 with CT 5); 2 and 1 for latency-bound launches.

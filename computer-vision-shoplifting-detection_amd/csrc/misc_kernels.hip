@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void sppf_pools_kernel(const float* src, int s
     const int b = blockIdx.x / cgroups, c0 = (blockIdx.x % cgroups) * POOL_C;
     const int npx = H * W, nq = POOL_C / 4;
     float* cur = pl;
-    float* nxt = pl + (size_t)npx * POOL_C;
+    float* tmp = pl + (size_t)npx * POOL_C;
     const float NEG = -__builtin_huge_valf();
     for (int i = threadIdx.x; i < npx * nq; i += 256) {
         const int p = i / nq, q = i % nq;
@@ -243,23 +243,35 @@ __global__ __launch_bounds__(256) void sppf_pools_kernel(const float* src, int s
         *(f32x4*)(cur + p * POOL_C + 4 * q) = v;
     }
     __syncthreads();
+    // a 5x5 max is a 5-wide row max followed by a 5-tall column max (max is associative and exact): 10 LDS reads per output
+    // and pool instead of 25
     for (int pass = 0; pass < 3; ++pass) {
-        for (int i = threadIdx.x; i < npx * nq; i += 256) {
+        for (int i = threadIdx.x; i < npx * nq; i += 256) {                 // rows: cur -> tmp
+            const int p = i / nq, q = i % nq;
+            const int y = p / W, x = p - y * W;
+            f32x4 m = (f32x4){NEG, NEG, NEG, NEG};
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int xx = x + dx;
+                if ((unsigned)xx >= (unsigned)W) continue;
+                const f32x4 v = *(const f32x4*)(cur + (y * W + xx) * POOL_C + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]);
+            }
+            *(f32x4*)(tmp + p * POOL_C + 4 * q) = m;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < npx * nq; i += 256) {                 // columns: tmp -> cur (+ the global store)
             const int p = i / nq, q = i % nq;
             const int y = p / W, x = p - y * W;
             f32x4 m = (f32x4){NEG, NEG, NEG, NEG};
             for (int dy = -2; dy <= 2; ++dy) {
                 const int yy = y + dy;
                 if ((unsigned)yy >= (unsigned)H) continue;
-                for (int dx = -2; dx <= 2; ++dx) {
-                    const int xx = x + dx;
-                    if ((unsigned)xx >= (unsigned)W) continue;
-                    const f32x4 v = *(const f32x4*)(cur + (yy * W + xx) * POOL_C + 4 * q);
+                const f32x4 v = *(const f32x4*)(tmp + (yy * W + x) * POOL_C + 4 * q);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]);
-                }
+                for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]);
             }
-            *(f32x4*)(nxt + p * POOL_C + 4 * q) = m;
+            *(f32x4*)(cur + p * POOL_C + 4 * q) = m;                        // cur's old value at p is only read through tmp now
             if (c0 + 4 * q < C) {
                 float* d = dst + ((size_t)b * npx + p) * dst_cs + pass * C + c0 + 4 * q;
                 if (c0 + 4 * q + 3 < C) *(f32x4*)d = m;
@@ -267,7 +279,6 @@ __global__ __launch_bounds__(256) void sppf_pools_kernel(const float* src, int s
             }
         }
         __syncthreads();
-        float* t = cur; cur = nxt; nxt = t;
     }
 }
 
@@ -312,6 +323,7 @@ const char* launch_sppf_pools(const float* src, int src_cs, float* dst, int dst_
     int pc = 0;
     for (int c = 16; c >= 4; c >>= 1)
         if ((size_t)2 * H * W * c * sizeof(float) <= 48 * 1024) { pc = c; break; }
+    while (pc > 4 && (long)B * ((C + pc - 1) / pc) < 256) pc >>= 1;      // small batches: more, narrower blocks (one per CU at least)
     if (!pc) {
         const int c4n = C / 4;
         const long total = (long)B * H * W * c4n;

@@ -308,9 +308,14 @@ __global__ __launch_bounds__(NMS_SORT_THREADS) void nms_sort_kernel(NmsArgs a, i
     if (tid == 0) cand_counts[b] = n < a.max_nms ? n : a.max_nms;     // "if n > max_nms: keep the top max_nms by conf"
 }
 
-// Kernel 2 (one wave per image): greedy suppression over the sorted candidates in chunks of 64, stopping at
-// max_det kept boxes, then scale-back and row packing.
+// Kernel 2 (one block of NMS_WAVES waves per image): greedy suppression over the sorted candidates in chunks of 64, stopping
+// at max_det kept boxes, then scale-back and row packing.  The test of a chunk against the boxes kept so far -- the bulk of
+// the work: candidates x kept IoUs, each with an IEEE division -- is split over the waves (wave w takes kept boxes w,
+// w + NMS_WAVES, ...; the survivor masks are AND-ed through LDS); the greedy pass inside the chunk is inherently serial and is
+// run redundantly by every wave, which keeps the kept count uniform without a broadcast.  Decisions are those of the
+// sequential algorithm (torchvision.ops.nms order): a candidate dies iff some earlier kept box overlaps it.
 constexpr int NMS_MAX_DET = 1024;
+constexpr int NMS_WAVES = 8;
 
 struct CandBox { float x1, y1, x2, y2, area; };
 
@@ -323,16 +328,17 @@ __device__ __forceinline__ bool iou_gt(const CandBox& i, const CandBox& j, float
     return ovr > thr;
 }
 
-__global__ __launch_bounds__(64) void nms_greedy_kernel(NmsArgs a, const int* cand_counts) {
+__global__ __launch_bounds__(64 * NMS_WAVES) void nms_greedy_kernel(NmsArgs a, const int* cand_counts) {
     __shared__ float kx1[NMS_MAX_DET], ky1[NMS_MAX_DET], kx2[NMS_MAX_DET], ky2[NMS_MAX_DET], kar[NMS_MAX_DET];
     __shared__ int kan[NMS_MAX_DET];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ unsigned long long survive[2][NMS_WAVES];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long* keys = a.keys + (size_t)b * a.Apow2;
     const float* pred = a.pred + (size_t)b * a.A * a.no;
     const float2* best = a.best + (size_t)b * a.A;
     const int n = cand_counts[b];
-    int nk = 0;
-    for (int base = 0; base < n && nk < a.max_det; base += 64) {
+    int nk = 0, it = 0;
+    for (int base = 0; base < n && nk < a.max_det; base += 64, ++it) {
         const int j = base + lane;
         const bool valid = j < n;
         int an = 0;
@@ -348,28 +354,35 @@ __global__ __launch_bounds__(64) void nms_greedy_kernel(NmsArgs a, const int* ca
             me.area = (me.x2 - me.x1) * (me.y2 - me.y1);
         }
         bool alive = valid;
-        for (int k = 0; k < nk; ++k) {
+        for (int k = wave; k < nk; k += NMS_WAVES) {               // this wave's share of the kept boxes
             const CandBox kb = {kx1[k], ky1[k], kx2[k], ky2[k], kar[k]};
             if (alive && iou_gt(kb, me, a.iou)) alive = false;
         }
-        unsigned long long mask = __ballot(alive);
-        while (mask) {
+        const unsigned long long mine = __ballot(alive);
+        if (lane == 0) survive[it & 1][wave] = mine;
+        __syncthreads();
+        unsigned long long all = ~0ull;
+#pragma unroll
+        for (int w = 0; w < NMS_WAVES; ++w) all &= survive[it & 1][w];
+        alive = (all >> lane) & 1ull;
+        unsigned long long mask = all;
+        while (mask) {                                              // greedy pass inside the chunk (every wave, identically)
             const int jj = __ffsll((long long)mask) - 1;
             CandBox kb;
             kb.x1 = __shfl(me.x1, jj); kb.y1 = __shfl(me.y1, jj); kb.x2 = __shfl(me.x2, jj); kb.y2 = __shfl(me.y2, jj);
             kb.area = __shfl(me.area, jj);
-            if (lane == jj) { kx1[nk] = me.x1; ky1[nk] = me.y1; kx2[nk] = me.x2; ky2[nk] = me.y2; kar[nk] = me.area; kan[nk] = an; }
+            if (wave == 0 && lane == jj) { kx1[nk] = me.x1; ky1[nk] = me.y1; kx2[nk] = me.x2; ky2[nk] = me.y2; kar[nk] = me.area; kan[nk] = an; }
             ++nk;
             if (nk >= a.max_det) break;
             if (alive && lane > jj && iou_gt(kb, me, a.iou)) alive = false;
             mask = __ballot(alive && lane > jj);
         }
-        __syncthreads();
+        __syncthreads();                                            // the kept arrays are complete before the next chunk reads them
     }
     __syncthreads();
-    if (lane == 0) a.out_counts[b] = nk;
+    if (threadIdx.x == 0) a.out_counts[b] = nk;
     mi355_det* rows = (mi355_det*)a.out_rows + (size_t)b * a.max_det;
-    for (int k = lane; k < nk; k += 64) {
+    for (int k = threadIdx.x; k < nk; k += 64 * NMS_WAVES) {
         const int an = kan[k];
         const float* p = pred + (size_t)an * a.no;
         const float hw = p[2] / 2.0f, hh = p[3] / 2.0f;
@@ -405,7 +418,7 @@ const char* launch_nms(const NmsArgs& a, hipStream_t st) {
     // cand_counts lives in the tail of out_counts' allocation: out_counts[B .. 2B)
     int* cand_counts = a.out_counts + a.B;
     hipLaunchKernelGGL(nms_sort_kernel, dim3(a.B), dim3(NMS_SORT_THREADS), 0, st, a, cand_counts);
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(a.B), dim3(64), 0, st, a, cand_counts);
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(a.B), dim3(64 * NMS_WAVES), 0, st, a, cand_counts);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
