@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmi355yolo.so")
+# MI355_YOLO_LIB: load another build of the same ABI (kernel experiments: tools/ab_build.sh); the product never sets it
+LIB_PATH = os.environ.get("MI355_YOLO_LIB") or os.path.join(HERE, "libmi355yolo.so")
 MAX_KPT_FLOATS = 51
 
 
@@ -66,6 +67,8 @@ SIGNATURES = {
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, _i32p]),
     "mi355_op_conv2d_f16": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i32p]),
+    "mi355_op_conv2d_fused": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, _i32p]),
     "mi355_bench_conv2d": (C.c_int, [C.c_int] * 12 + [_f32p, _i32p, C.c_char_p, C.c_int]),
     "mi355_bench_conv2d_f16": (C.c_int, [C.c_int] * 12 + [_f32p, _i32p, C.c_char_p, C.c_int]),
     "mi355_op_stem": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,

@@ -111,8 +111,11 @@ __device__ __forceinline__ void store_tile(f32x4 v, const float* bias, int act, 
 // of the first conv's channels in LDS ([pixel][channel], exactly the image a 1x1 kernel would have staged from HBM), and
 // the same four waves then run the 1x1 from there -- the intermediate tensor is never written to or read from HBM.
 // Values, operation order and therefore bits are those of the two separate launches.
+#ifndef MI355_V1_MINWAVES
+#define MI355_V1_MINWAVES 1      // A/B knob (tools/ab_build.sh): min waves per SIMD asked of the register allocator for PT*CT == 4
+#endif
 template <int KS, int STRIDE, int PT, int CT, int WP, bool F2 = false>
-__global__ __launch_bounds__(256) void conv_igemm_f32(ConvKArgs a) {
+__global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : 1)) void conv_igemm_f32(ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int WC = 4 / WP;
     constexpr int TAPS = KS * KS;

@@ -1276,6 +1276,48 @@ int mi355_op_conv2d_f16(int device_id, const float* x, int n, int h, int w, int 
                           out_f32 != 0);
 }
 
+// Conv3x3 (+bias+SiLU) -> Conv1x1 (+bias, optional SiLU) as ONE fused launch (conv_igemm_f32<..., F2 = true>): the parity hook of
+// the fused pairs the engine runs (stride-2 conv -> C2f.cv1, head branch [1] -> [2]).
+int mi355_op_conv2d_fused(int device_id, const float* x, int n, int h, int w, int cin, const float* w1_oihw, const float* b1, int c1,
+                          int stride, const float* w2_oihw, const float* b2, int c2, int silu2, float* y, int plan_index, int* n_plans) {
+    if (!x || !w1_oihw || !b1 || !w2_oihw || !b2 || !y || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || c1 <= 0 || c2 <= 0) return fail(MI355_EINVAL, "bad argument");
+    if ((stride != 1 && stride != 2) || (h % stride) || (w % stride)) return fail(MI355_EINVAL, "stride must be 1 or 2 and divide h and w");
+    HIPCHK(hipSetDevice(device_id));
+    const int ho = h / stride, wo = w / stride;
+    const int cs_in = round_up(cin, 4), cs_out = round_up(c2, 4);
+    const size_t npi = (size_t)n * h * w, npo = (size_t)n * ho * wo;
+    std::vector<float> xin(npi * cs_in, 0.f), yout(npo * cs_out, 0.f);
+    for (size_t p = 0; p < npi; ++p) std::memcpy(&xin[p * cs_in], x + p * cin, (size_t)cin * 4);
+    DevMem dm; float *d_x, *d_y, *d_w1, *d_b1, *d_w2, *d_b2, *d_z, *d_mid;
+    HIPCHK(dm.alloc(&d_z, 256)); HIPCHK(hipMemset(d_z, 0, 256));
+    HIPCHK(dm.alloc(&d_x, xin.size() * 4)); HIPCHK(hipMemcpy(d_x, xin.data(), xin.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(dm.alloc(&d_y, yout.size() * 4)); HIPCHK(hipMemset(d_y, 0, yout.size() * 4));
+    HIPCHK(dm.alloc(&d_mid, npo * round_up(c1, 4) * 4));          // the unfused destination of the first conv: must stay untouched
+    HIPCHK(hipMemset(d_mid, 0, npo * round_up(c1, 4) * 4));
+    auto upload_conv = [&](const float* wt, const float* b, int co, int ci, int k, float** dw, float** db) -> int {
+        std::vector<float> pk(packed_weight_floats(co, ci, k)), bp(round_up(co, 16), 0.f);
+        pack_conv_weights(wt, co, ci, k, pk.data());
+        std::memcpy(bp.data(), b, (size_t)co * 4);
+        HIPCHK(dm.alloc(dw, pk.size() * 4)); HIPCHK(hipMemcpy(*dw, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(dm.alloc(db, bp.size() * 4)); HIPCHK(hipMemcpy(*db, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+        return MI355_OK;
+    };
+    int rc = upload_conv(w1_oihw, b1, c1, cin, 3, &d_w1, &d_b1); if (rc) return rc;
+    rc = upload_conv(w2_oihw, b2, c2, c1, 1, &d_w2, &d_b2); if (rc) return rc;
+    ConvArgs a{};
+    a.src = d_x; a.src_cs = cs_in; a.dst = d_mid; a.dst_cs = round_up(c1, 4); a.wpk = d_w1; a.bias = d_b1; a.zeros = d_z;
+    a.B = n; a.Hin = h; a.Win = w; a.Hout = ho; a.Wout = wo; a.Cin = cin; a.Cout = c1; a.k = 3; a.stride = stride; a.pad = 1; a.act = 1;
+    a.f2_wpk = d_w2; a.f2_bias = d_b2; a.f2_dst = d_y; a.f2_dst_cs = cs_out; a.f2_cout = c2; a.f2_act = silu2 ? 1 : 0;
+    std::vector<ConvLaunch> cands;
+    KCHK(plan_conv_candidates(a, &cands));
+    if (n_plans) *n_plans = (int)cands.size();
+    KCHK(run_conv(cands[(size_t)(plan_index < 0 ? 0 : plan_index) % cands.size()], nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(yout.data(), d_y, yout.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < npo; ++p) std::memcpy(y + p * c2, &yout[p * cs_out], (size_t)c2 * 4);
+    return MI355_OK;
+}
+
 static int bench_conv2d_impl(int device_id, int n, int h, int w, int cin, int cout, int k, int stride, int silu, int residual,
                              int plan_index, int iters, float* avg_ms, int* n_plans, char* plan_desc, int plan_desc_len, bool half) {
     if (!avg_ms || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || iters <= 0) return fail(MI355_EINVAL, "bad argument");

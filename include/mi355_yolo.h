@@ -160,6 +160,13 @@ int  mi355_op_conv2d(int device_id, const float* x, int n, int h, int w, int cin
 int  mi355_op_conv2d_f16(int device_id, const float* x, int n, int h, int w, int cin, const float* w_oihw,
                          const float* bias, int cout, int k, int stride, int silu, const float* residual, float* y,
                          int out_f32, int plan_index, int* n_plans);
+/* Conv3x3 (stride 1|2, pad 1) + bias + SiLU -> Conv1x1 + bias (+SiLU if silu2) run as ONE fused launch, the way the engine runs
+ * a 3x3 conv whose only reader is a pointwise conv (the first conv's output never leaves the chip).  x[n][h][w][cin],
+ * w1[c1][cin][3][3], b1[c1], w2[c2][c1][1][1], b2[c2] -> y[n][h/stride][w/stride][c2]; must equal the two convs run separately,
+ * bit for bit, for every plan_index. */
+int  mi355_op_conv2d_fused(int device_id, const float* x, int n, int h, int w, int cin, const float* w1_oihw, const float* b1,
+                           int c1, int stride, const float* w2_oihw, const float* b2, int c2, int silu2, float* y,
+                           int plan_index, int* n_plans);
 /* Device-resident timing of one conv launch plan on random data (diagnostics / tuning): average milliseconds over
  * `iters` back-to-back launches of candidate plan `plan_index`; plan_desc (optional) receives a description. */
 int  mi355_bench_conv2d(int device_id, int n, int h, int w, int cin, int cout, int k, int stride, int silu, int residual,

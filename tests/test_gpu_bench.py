@@ -31,6 +31,9 @@ def test_bench_line_single_gpu():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert c["parity_vs_gpu"]["rows_bit_exact_vs_canonical_order_oracle"] is True
+    e = c["parity_vs_gpu"]["err_vs_f64_px"]                     # both fp32 implementations against the float64 yardstick
+    assert e["gpu"]["mean"] > 0 and e["torch_cpu"]["mean"] > 0 and e["gpu"]["mean"] <= 1.1 * e["torch_cpu"]["mean"]
+    assert "configs" not in d and "host_fed_value" not in d   # those ride on the default headline workload only
 
 
 def test_bench_two_ranks_rehearsed_on_one_gpu():

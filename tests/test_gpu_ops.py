@@ -92,6 +92,35 @@ def test_every_launch_plan_gives_the_same_bits(n, h, w, cin, cout, k, stride):
                                       err_msg=f"plan {plan} of {n_plans}")
 
 
+@pytest.mark.parametrize("n,h,w,cin,c1,stride,c2,silu2", [
+    (2, 32, 32, 16, 32, 2, 32, True),        # model.1 -> model.2.cv1
+    (1, 40, 40, 64, 64, 1, 64, False),       # cv2[i][1] -> cv2[i][2] (box logits, no activation)
+    (1, 24, 40, 80, 80, 1, 80, False),       # cv3[i][1] -> cv3[i][2]: 5 cout tiles, 80 classes
+    (2, 20, 20, 51, 51, 1, 51, False),       # cv4[i][1] -> cv4[i][2]: ragged channel counts on both convs
+    (1, 20, 20, 64, 64, 1, 1, False),        # pose cls output (nc = 1)
+    (1, 16, 16, 128, 256, 2, 256, True),     # model.7 -> model.8.cv1: two staged chunks, 16 cout tiles
+    (1, 20, 20, 64, 128, 2, 128, True),      # batch-1 shape: small wave tiles among the candidates
+])
+def test_fused_conv_pair_equals_the_two_convs_for_every_plan(n, h, w, cin, c1, stride, c2, silu2):
+    """Conv3x3+SiLU -> Conv1x1 as one launch (first conv's output image stays in LDS) against the canonical-order oracle's
+    two separate convs: identical bits for every candidate launch plan (tile shapes, cout groups, wave-tile sizes)."""
+    from cvsd_amd import ops
+    from oracle import det
+    rng = np.random.default_rng(cin * 7 + c1 + c2 + stride)
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    w1 = (rng.standard_normal((c1, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b1 = rng.standard_normal(c1).astype(np.float32)
+    w2 = (rng.standard_normal((c2, c1, 1, 1)) / np.sqrt(c1)).astype(np.float32)
+    b2 = rng.standard_normal(c2).astype(np.float32)
+    ref = det.conv2d(det.conv2d(x, w1, b1, stride=stride, act=True), w2, b2, stride=1, act=silu2)
+    y, n_plans = ops.conv2d_fused(x, w1, b1, w2, b2, stride=stride, silu2=silu2, plan=0, return_n_plans=True)
+    np.testing.assert_array_equal(y, ref)
+    assert n_plans >= 2
+    for plan in range(1, n_plans):
+        np.testing.assert_array_equal(ops.conv2d_fused(x, w1, b1, w2, b2, stride=stride, silu2=silu2, plan=plan), ref,
+                                      err_msg=f"fused plan {plan} of {n_plans}")
+
+
 def test_conv2d_asymmetric_identity():
     """A = I check with an asymmetric operand (catches a transposed MFMA fragment map)."""
     from cvsd_amd import ops

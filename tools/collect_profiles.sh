@@ -10,10 +10,10 @@ rm -rf gpurun_out/${TAG}_trace gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write g
 export MI355_SCHED_LOG=1     # the engine prints its launch order (schedule, fused ops) for tools/layer_report.py
 # per-kernel durations are taken on ONE in-order stream (same kernels, same plans); the product overlaps independent branches on
 # 4 streams, which would smear the per-layer timings.  The PMC passes below run the default multi-stream configuration.
-MI355_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > gpurun_out/${TAG}_trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/${TAG}_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/${TAG}_write.log 2>&1
+MI355_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-configs "$@" > gpurun_out/${TAG}_trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-configs "$@" > gpurun_out/${TAG}_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-configs "$@" > gpurun_out/${TAG}_write.log 2>&1
 if [ "${MFMA:-0}" = "1" ]; then
-  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${TAG}_mfma -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/${TAG}_mfma.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${TAG}_mfma -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-configs "$@" > gpurun_out/${TAG}_mfma.log 2>&1
 fi
 ls gpurun_out/${TAG}_*/*/ | head -20

@@ -21,8 +21,10 @@ print(rep.stdout[-600:], rep.stderr[-2000:])
 sys.path.insert(0, ROOT)
 from cvsd_amd.graph import build_program, parse_model_name
 pg = build_program(*parse_model_name(model))
-n_conv = sum(1 for c in pg.convs if c.cin != 3)
-is_conv = lambda name: "conv_igemm" in name or "conv1x1_" in name
+# conv launches of one step: fewer than the module's convs (sibling convs merged, Conv3x3 -> Conv1x1 pairs fused where the
+# autotuner found that faster); bench.py reports the count it measured in the same process
+n_conv = json.loads([l for l in open(os.path.join(ROOT, "gpurun_out", f"{tag}_fetch.log")) if l.startswith('{"metric')][-1])["roofline"]["launches_per_step"]
+is_conv = lambda name: "conv_igemm" in name or "conv1x1_" in name or "conv_splitk" in name
 
 
 def conv_sum(pat, counter, passes=6):
@@ -50,6 +52,6 @@ try:
                                      "note": "sums over the conv dispatches of one step; GRBM_GUI_ACTIVE is the sum over the 8 XCDs"}
 except (IndexError, FileNotFoundError, ValueError):
     pass
-name = "r01_conv_traffic.json" if tag == "r01_v3" else f"{tag}_conv_traffic.json"
+name = "r01_conv_traffic.json" if tag == "r01_v3" else "r02_conv_traffic.json" if tag == "r02_v1" else f"{tag}_conv_traffic.json"
 json.dump(out, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
 print(json.dumps(out, indent=1))
