@@ -906,7 +906,7 @@ static int infer_impl(mi355_yolo* h, const uint8_t* src, bool src_on_device, int
     }
     if (h->counts_cap < 2 * n) {
         if (h->d_counts) (void)hipFree(h->d_counts); h->d_counts = nullptr; h->counts_cap = 0;
-        HIPCHK(hipMalloc(&h->d_counts, (size_t)2 * n * sizeof(int) + 2 * h->chunk * sizeof(int))); h->counts_cap = 2 * n;
+        HIPCHK(hipMalloc(&h->d_counts, (size_t)2 * n * sizeof(int) + 3 * h->chunk * sizeof(int))); h->counts_cap = 2 * n;   // + [counts | candidate counts | sort lengths] of one chunk
     }
     if (h->packed_cap < (size_t)n * max_det) {
         if (h->d_packed) (void)hipFree(h->d_packed); h->d_packed = nullptr; h->packed_cap = 0;
@@ -1432,7 +1432,7 @@ int mi355_op_nms(int device_id, const float* pred, int n, int nc, int extra, int
     const size_t pn = (size_t)n * no * anchors;
     HIPCHK(dm.alloc(&d_in, pn * 4)); HIPCHK(dm.alloc(&d_am, pn * 4)); HIPCHK(dm.alloc(&d_best, (size_t)n * anchors * sizeof(float2)));
     HIPCHK(dm.alloc(&d_keys, (size_t)n * ap2 * 8)); HIPCHK(dm.alloc(&d_rows, (size_t)n * max_det * sizeof(mi355_det)));
-    HIPCHK(dm.alloc(&d_counts, (size_t)2 * n * sizeof(int)));
+    HIPCHK(dm.alloc(&d_counts, (size_t)3 * n * sizeof(int)));
     HIPCHK(hipMemcpy(d_in, pred, pn * 4, hipMemcpyHostToDevice));
     if (n_classes > 0 && classes) {
         std::vector<unsigned> m((nc + 31) / 32, 0u);

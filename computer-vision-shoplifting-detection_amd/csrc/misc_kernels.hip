@@ -13,6 +13,12 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float silu_m(float v) { return det_silu(v); }
+// half=True path only (the value is rounded to fp16 next; same formulation as conv_igemm_f16.hip: 1e-7 relative on the
+// hardware transcendental units instead of the 32-instruction bit-exact form)
+__device__ __forceinline__ float silu_fast(float v) {
+    const float e = __builtin_amdgcn_exp2f(v * -1.44269504088896341f);
+    return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
 // ---------------------------------------------------------------------------------------------- stem
 // model.0: Conv(3 -> Cout, k, s) on the letterboxed uint8 BGR frame.  Fuses the rest of
@@ -148,10 +154,10 @@ __global__ __launch_bounds__(256) void stem_mfma_u8(StemArgs a) {
                 if (c + 3 < a.Cout) {
                     f16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)silu_m(v[j] + a.bias[c + j]);
+                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)silu_fast(v[j] + a.bias[c + j]);
                     *(f16x4*)dh = o;
                 } else {
-                    for (int j = 0; j < 4 && c + j < a.Cout; ++j) dh[j] = (_Float16)silu_m(v[j] + a.bias[c + j]);
+                    for (int j = 0; j < 4 && c + j < a.Cout; ++j) dh[j] = (_Float16)silu_fast(v[j] + a.bias[c + j]);
                 }
             } else {
                 float* d = a.dst + po * a.dst_cs + c;
@@ -364,7 +370,19 @@ __global__ __launch_bounds__(256) void sppf_pools_f16_kernel(const _Float16* src
         *(f16x8*)(cur + p * POOL_C + 8 * q) = v;
     }
     __syncthreads();
-    for (int pass = 0; pass < 3; ++pass) {
+    for (int pass = 0; pass < 3; ++pass) {                                 // 5x5 max = row max, then column max (see sppf_pools_kernel)
+        for (int i = threadIdx.x; i < npx * nq; i += 256) {
+            const int p = i / nq, q = i % nq;
+            const int y = p / W, x = p - y * W;
+            f16x8 m = NEG8;
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int xx = x + dx;
+                if ((unsigned)xx >= (unsigned)W) continue;
+                m = max8(m, *(const f16x8*)(cur + (y * W + xx) * POOL_C + 8 * q));
+            }
+            *(f16x8*)(nxt + p * POOL_C + 8 * q) = m;
+        }
+        __syncthreads();
         for (int i = threadIdx.x; i < npx * nq; i += 256) {
             const int p = i / nq, q = i % nq;
             const int y = p / W, x = p - y * W;
@@ -372,17 +390,12 @@ __global__ __launch_bounds__(256) void sppf_pools_f16_kernel(const _Float16* src
             for (int dy = -2; dy <= 2; ++dy) {
                 const int yy = y + dy;
                 if ((unsigned)yy >= (unsigned)H) continue;
-                for (int dx = -2; dx <= 2; ++dx) {
-                    const int xx = x + dx;
-                    if ((unsigned)xx >= (unsigned)W) continue;
-                    m = max8(m, *(const f16x8*)(cur + (yy * W + xx) * POOL_C + 8 * q));
-                }
+                m = max8(m, *(const f16x8*)(nxt + (yy * W + x) * POOL_C + 8 * q));
             }
-            *(f16x8*)(nxt + p * POOL_C + 8 * q) = m;
+            *(f16x8*)(cur + p * POOL_C + 8 * q) = m;
             if (c0 + 8 * q < C) *(f16x8*)(dst + ((size_t)b * npx + p) * dst_cs + pass * C + c0 + 8 * q) = m;
         }
         __syncthreads();
-        _Float16* t = cur; cur = nxt; nxt = t;
     }
 }
 

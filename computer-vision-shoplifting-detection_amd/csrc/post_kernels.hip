@@ -272,12 +272,10 @@ __device__ void bitonic_sort_hybrid(unsigned long long* keys, unsigned long long
     }
 }
 
-__global__ __launch_bounds__(NMS_SORT_THREADS) void nms_sort_kernel(NmsArgs a, int* cand_counts) {
-    __shared__ unsigned long long skeys[NMS_LDS_KEYS];
-    __shared__ int scount;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    unsigned long long* keys = a.keys + (size_t)b * a.Apow2;
-    if (tid == 0) scount = 0;
+// candidate filter of one image: keys[0 .. n) = (~score bits, anchor index) of the anchors that pass conf / class mask, padded with
+// ~0 up to the next power of two n2; returns n2 (block-uniform), *n_out = n
+__device__ int nms_collect(const NmsArgs& a, int b, unsigned long long* keys, int* scount, int tid, int* n_out) {
+    if (tid == 0) *scount = 0;
     __syncthreads();
     const float2* best = a.best + (size_t)b * a.A;
     for (int an = tid; an < a.A; an += NMS_SORT_THREADS) {
@@ -285,16 +283,27 @@ __global__ __launch_bounds__(NMS_SORT_THREADS) void nms_sort_kernel(NmsArgs a, i
         bool ok = bc.x > a.conf;
         if (ok && a.class_mask) { const int c = (int)bc.y; ok = (a.class_mask[c >> 5] >> (c & 31)) & 1u; }
         if (ok) {
-            const int pos = atomicAdd(&scount, 1);
+            const int pos = atomicAdd(scount, 1);
             keys[pos] = ((unsigned long long)(~__float_as_uint(bc.x)) << 32) | (unsigned)an;
         }
     }
     __syncthreads();
-    const int n = scount;
+    const int n = *scount;
     int n2 = 1;
     while (n2 < n) n2 <<= 1;
     for (int i = n + tid; i < n2; i += NMS_SORT_THREADS) keys[i] = ~0ull;
     __syncthreads();
+    *n_out = n;
+    return n2;
+}
+
+__global__ __launch_bounds__(NMS_SORT_THREADS) void nms_sort_kernel(NmsArgs a, int* cand_counts) {
+    __shared__ unsigned long long skeys[NMS_LDS_KEYS];
+    __shared__ int scount;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    unsigned long long* keys = a.keys + (size_t)b * a.Apow2;
+    int n = 0;
+    const int n2 = nms_collect(a, b, keys, &scount, tid, &n);
     if (n2 > 1) {
         if (n2 <= NMS_LDS_KEYS) {
             for (int i = tid; i < n2; i += NMS_SORT_THREADS) skeys[i] = keys[i];
@@ -306,6 +315,69 @@ __global__ __launch_bounds__(NMS_SORT_THREADS) void nms_sort_kernel(NmsArgs a, i
         }
     }
     if (tid == 0) cand_counts[b] = n < a.max_nms ? n : a.max_nms;     // "if n > max_nms: keep the top max_nms by conf"
+}
+
+// ---- the same sort spread over many blocks, for maps with more than 16384 anchors (1280x1280: 33,600 anchors, tens of thousands of
+// candidates at low conf): one block per image sorting 32k keys took 0.68 ms per step, at any batch.  The bitonic network is cut into
+// launches: collect (one block per image), chunk-local stages k <= 4096 (one block per 4096-key chunk, in LDS), then per merge stage
+// k the few long-distance steps (j >= 4096, global memory, all chunks in parallel) and the LDS-resident rest (j < 4096).  Blocks
+// beyond an image's padded length exit at once.  Keys are unique, so the result is the sequence the one-block sort gives.
+__global__ __launch_bounds__(NMS_SORT_THREADS) void nms_collect_kernel(NmsArgs a, int* cand_counts, int* sort_len) {
+    __shared__ int scount;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int n = 0;
+    const int n2 = nms_collect(a, b, a.keys + (size_t)b * a.Apow2, &scount, tid, &n);
+    if (tid == 0) { cand_counts[b] = n < a.max_nms ? n : a.max_nms; sort_len[b] = n2; }
+}
+
+__global__ __launch_bounds__(NMS_SORT_THREADS) void nms_chunk_sort_kernel(NmsArgs a, const int* sort_len, int chunks) {
+    __shared__ unsigned long long sk[NMS_LDS_KEYS];
+    const int b = blockIdx.x / chunks, base = (blockIdx.x % chunks) * NMS_LDS_KEYS, tid = threadIdx.x;
+    const int n2 = sort_len[b];
+    if (base >= n2 || n2 < 2) return;
+    unsigned long long* keys = a.keys + (size_t)b * a.Apow2;
+    const int len = n2 < NMS_LDS_KEYS ? n2 : NMS_LDS_KEYS;            // a short sequence is one (partial) chunk
+    for (int l = tid; l < len; l += NMS_SORT_THREADS) sk[l] = keys[base + l];
+    __syncthreads();
+    for (int k = 2; k <= len; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int l = tid; l < len; l += NMS_SORT_THREADS) {
+                const int lxj = l ^ j;
+                if (lxj > l) {
+                    const unsigned long long x = sk[l], y = sk[lxj];
+                    const bool up = ((base + l) & k) == 0;
+                    if ((x > y) == up) { sk[l] = y; sk[lxj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int l = tid; l < len; l += NMS_SORT_THREADS) keys[base + l] = sk[l];
+}
+
+__global__ __launch_bounds__(NMS_SORT_THREADS) void nms_global_step_kernel(NmsArgs a, const int* sort_len, int blocks_per_image, int k, int j) {
+    const int b = blockIdx.x / blocks_per_image;
+    const int n2 = sort_len[b];
+    if (k > n2) return;
+    unsigned long long* keys = a.keys + (size_t)b * a.Apow2;
+    const int i = (blockIdx.x % blocks_per_image) * NMS_SORT_THREADS + threadIdx.x;       // one thread per lower partner
+    // enumerate the indices whose bit j is clear: insert a 0 at bit position log2(j)
+    const int lo = i & (j - 1), idx = ((i - lo) << 1) | lo;
+    if (idx >= n2) return;
+    const unsigned long long x = keys[idx], y = keys[idx | j];
+    const bool up = (idx & k) == 0;
+    if ((x > y) == up) { keys[idx] = y; keys[idx | j] = x; }
+}
+
+__global__ __launch_bounds__(NMS_SORT_THREADS) void nms_lds_steps_kernel(NmsArgs a, const int* sort_len, int chunks, int k) {
+    __shared__ unsigned long long sk[NMS_LDS_KEYS];
+    const int b = blockIdx.x / chunks, base = (blockIdx.x % chunks) * NMS_LDS_KEYS, tid = threadIdx.x;
+    const int n2 = sort_len[b];
+    if (k > n2 || base >= n2) return;
+    unsigned long long* keys = a.keys + (size_t)b * a.Apow2;
+    for (int l = tid; l < NMS_LDS_KEYS; l += NMS_SORT_THREADS) sk[l] = keys[base + l];
+    __syncthreads();
+    bitonic_steps_lds(sk, base, k, NMS_LDS_KEYS >> 1, tid);
+    for (int l = tid; l < NMS_LDS_KEYS; l += NMS_SORT_THREADS) keys[base + l] = sk[l];
 }
 
 // Kernel 2 (one block of NMS_WAVES waves per image): greedy suppression over the sorted candidates in chunks of 64, stopping
@@ -417,7 +489,21 @@ const char* launch_nms(const NmsArgs& a, hipStream_t st) {
     if (a.max_det < 1 || a.max_det > NMS_MAX_DET) return "nms: max_det must be in [1, 1024]";
     // cand_counts lives in the tail of out_counts' allocation: out_counts[B .. 2B)
     int* cand_counts = a.out_counts + a.B;
-    hipLaunchKernelGGL(nms_sort_kernel, dim3(a.B), dim3(NMS_SORT_THREADS), 0, st, a, cand_counts);
+    if (a.Apow2 > 4 * NMS_LDS_KEYS) {
+        // big maps: the sort as a sequence of wide launches (see nms_collect_kernel); sort lengths live at out_counts[2B .. 3B)
+        int* sort_len = a.out_counts + 2 * a.B;
+        const int chunks = a.Apow2 / NMS_LDS_KEYS;
+        hipLaunchKernelGGL(nms_collect_kernel, dim3(a.B), dim3(NMS_SORT_THREADS), 0, st, a, cand_counts, sort_len);
+        hipLaunchKernelGGL(nms_chunk_sort_kernel, dim3(a.B * chunks), dim3(NMS_SORT_THREADS), 0, st, a, sort_len, chunks);
+        const int bpi = a.Apow2 / 2 / NMS_SORT_THREADS;
+        for (int k = 2 * NMS_LDS_KEYS; k <= a.Apow2; k <<= 1) {
+            for (int j = k >> 1; j >= NMS_LDS_KEYS; j >>= 1)
+                hipLaunchKernelGGL(nms_global_step_kernel, dim3(a.B * bpi), dim3(NMS_SORT_THREADS), 0, st, a, sort_len, bpi, k, j);
+            hipLaunchKernelGGL(nms_lds_steps_kernel, dim3(a.B * chunks), dim3(NMS_SORT_THREADS), 0, st, a, sort_len, chunks, k);
+        }
+    } else {
+        hipLaunchKernelGGL(nms_sort_kernel, dim3(a.B), dim3(NMS_SORT_THREADS), 0, st, a, cand_counts);
+    }
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(a.B), dim3(64 * NMS_WAVES), 0, st, a, cand_counts);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);

@@ -212,6 +212,21 @@ def test_nms_matches_oracle(nc, extra, a, frac, classes, max_det):
         np.testing.assert_array_equal(rows, wr.numpy())              # same fp32 op order -> bit-exact rows
 
 
+@pytest.mark.parametrize("n,frac", [(2, 0.03), (2, 0.3), (1, 0.9)])
+def test_nms_on_a_1280_map_uses_the_multi_launch_sort(n, frac):
+    """33,600 anchors (a 1280x1280 input): the candidate sort runs as a sequence of wide launches (collect, chunk-local stages,
+    global + LDS merge steps) instead of one block per image; 1k / 10k / 30k candidates = one partial chunk / 4 chunks / 8 chunks"""
+    from cvsd_amd import ops
+    from oracle import yolo_oracle as O
+    rng = np.random.default_rng(int(frac * 100))
+    pred = _random_pred(rng, n, 80, 0, 33600, frac)
+    got = ops.nms(pred, 80, conf=0.25, iou=0.7, max_det=300)
+    want, idxs = O.non_max_suppression(torch.from_numpy(pred), 0.25, 0.7, max_det=300, nc=80, return_idxs=True)
+    for (rows, anchors), wr, wi in zip(got, want, idxs):
+        np.testing.assert_array_equal(anchors, wi.numpy())
+        np.testing.assert_array_equal(rows, wr.numpy())
+
+
 def test_nms_score_ties_are_stable():
     """equal scores keep ascending anchor order (torch's stable sort)"""
     from cvsd_amd import ops
