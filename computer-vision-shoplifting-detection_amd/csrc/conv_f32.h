@@ -112,7 +112,8 @@ __device__ __forceinline__ void store_tile(f32x4 v, const float* bias, int act, 
 // the same four waves then run the 1x1 from there -- the intermediate tensor is never written to or read from HBM.
 // Values, operation order and therefore bits are those of the two separate launches.
 #ifndef MI355_V1_MINWAVES
-#define MI355_V1_MINWAVES 1      // A/B knob (tools/ab_build.sh): min waves per SIMD asked of the register allocator for PT*CT == 4
+#define MI355_V1_MINWAVES 4      // min waves per SIMD asked of the register allocator for the PT*CT == 4 instances (A/B with
+                                 // tools/ab_build.sh: 1 -> 4 costs a 12-byte spill outside the loop, buys 2-3 % on the stride-2 layers, 0-1 % elsewhere)
 #endif
 template <int KS, int STRIDE, int PT, int CT, int WP, bool F2 = false>
 __global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : 1)) void conv_igemm_f32(ConvKArgs a) {
