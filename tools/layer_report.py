@@ -18,7 +18,7 @@ sched_log = sys.argv[6] if len(sys.argv) > 6 else None      # bench log with the
 rows = [r for r in csv.DictReader(open(path)) if "mi355" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Dispatch_Id"]))              # host enqueue order (kernels of different streams overlap in time)
 kind = {OP_STEM: "stem_", OP_CONV: "conv", OP_UPSAMPLE: "upsample2x", OP_SPPF_POOL: "sppf_pools"}
-tail = ["decode_kernel", "nms_sort_kernel", "nms_greedy_kernel"]
+tail = ["decode_kernel"]          # ... followed by the NMS launches (nms_sort + nms_greedy, or the multi-launch sort of big maps), folded into one row
 orders = [list(range(len(prog.ops)))]                       # program order (profiling passes) ...
 launched = {i: True for i in range(len(prog.ops))}
 if sched_log and os.path.exists(sched_log):
@@ -45,11 +45,21 @@ while i < len(rows):
         ops_l, names = hit
         by_op = {op: rows[i + j] for j, op in enumerate(ops_l)}
         prog_l = [k for k in range(len(prog.ops)) if launched[k]]
-        passes.append([by_op[k] for k in prog_l] + rows[i + len(ops_l):i + len(names)]); i += len(names)
+        e = i + len(names)
+        nms = []
+        while e < len(rows) and "nms_" in rows[e]["Kernel_Name"]:
+            nms.append(rows[e]); e += 1
+        nms_row = dict(nms[0]) if nms else None
+        if nms_row:                                          # one synthetic row: total NMS time of the pass
+            nms_row["Kernel_Name"] = f"nms ({len(nms)} launches)"
+            nms_row["Start_Timestamp"] = "0"
+            nms_row["End_Timestamp"] = str(sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in nms))
+        passes.append([by_op[k] for k in prog_l] + rows[i + len(ops_l):i + len(names)] + ([nms_row] if nms_row else [])); i = e
     else:
         i += 1
 prog_l = [k for k in range(len(prog.ops)) if launched[k]]
-seq = [kind[prog.ops[k].type] for k in prog_l] + tail
+seq = [kind[prog.ops[k].type] for k in prog_l] + tail + ["nms"]
+passes = [p for p in passes if len(p) == len(seq)]
 print(f"{len(passes)} passes of {len(seq)} launches matched ({model}, chunk {chunk})")
 tot = 0.0
 print(f"{'op':40s} {'kernel<KS,S,PT,CT,WP>':24s} {'shape':30s} {'grid':>12s} {'lds':>6s} {'vgpr':>5s} {'us':>8s} {'TFLOP/s':>8s} {'GB/s':>7s}")
