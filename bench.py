@@ -35,7 +35,7 @@ N_BASE_FRAMES = 16              # frames made by tools/synth.py on the host (the
 # BASELINE.json configs 2-5 as stated, per GPU (config 4 shards batch 64 over 8 GPUs: 8 per GPU, and 64 per GPU for the
 # throughput form; config 5 shards batch 16 over 8 GPUs: 2 per GPU, and 16 on one GPU): (model, size, batch, half, steps, warmup)
 EXTRA_CONFIGS = [
-    ("yolov8n", 640, 1, False, 300, 30),
+    ("yolov8n", 640, 1, False, 600, 100),
     ("yolov8n-pose", 640, 32, False, 40, 5),
     ("yolov8s-pose", 640, 8, False, 60, 8),
     ("yolov8s-pose", 640, 64, False, 12, 3),
