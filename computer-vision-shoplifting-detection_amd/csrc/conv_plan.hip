@@ -84,8 +84,11 @@ std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int ci
     // MFMA -- the f16 MFMA retires a 1-KiB fragment pair in 16 cycles, so those kernels are bound by L1/L2 fragment traffic.
     // fp32: 0 = the default (4, or 3 with CT 5); 2 and 1 for latency-bound launches.
     std::vector<int> pt_sel = {0};
+    static const int small_k_pt2 = env_int("MI355_SMALLK_PT2", 1);
     if (half) pt_sel.push_back(8);
     else if (latency_bound) { pt_sel.push_back(2); pt_sel.push_back(1); }
+    else if (small_k_pt2 && ks == 3 && cin16 * ks * ks <= 288) pt_sel.push_back(2);   // short K loops: staging + epilogue weigh as much
+                                                                                     // as the MFMAs, so more (narrower) waves per SIMD pay
     for (int PTsel : pt_sel)
     for (int WC = 1; WC <= 4; WC *= 2)
         for (int CT = 1; CT <= 5; ++CT) {
