@@ -149,7 +149,9 @@ struct mi355_yolo {
     // program's dependency DAG (RAW on buffer slices), in depth order, a chain inheriting its producer's stream; an op waits
     // on the events of producers that live on other streams.  Measured gain: +14 % at batch 1, +10 % at 8, +3 % at 64 and
     // still +2 % at 512 (the tails of one launch fill with the blocks of another); MI355_STREAMS=1 turns it off.
-    int n_streams = 4, streams_max_batch = 1 << 30;
+    int n_streams = 4, streams_max_batch = 1 << 30, streams_min_batch = 6;   // below 6 frames per pass one in-order stream is faster
+                                                  // (round 2, merged + fused program: batch 1 1,990 vs 1,844 frames/s, batch 4 4,780 vs 4,530;
+                                                  // batch 8 6,150 vs 6,360): the cross-stream event waits cost more than the overlap buys
     std::vector<hipStream_t> aux;             // streams 1 .. n_streams-1 (0 = `stream`)
     std::vector<hipEvent_t> op_done;          // per op: recorded after its launch when someone on another stream waits for it
     hipEvent_t ev_fork = nullptr;
@@ -366,6 +368,7 @@ static int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
     HIPCHK(hipMemset(h->zeros, 0, 256));
     if (const char* e = getenv("MI355_STREAMS")) h->n_streams = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("MI355_STREAMS_MAX_BATCH")) h->streams_max_batch = atoi(e);
+    if (const char* e = getenv("MI355_STREAMS_MIN_BATCH")) h->streams_min_batch = atoi(e);
     return build_schedule(h);
 }
 
@@ -777,7 +780,7 @@ static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, c
     };
     // several streams along the dependency DAG (profiling keeps the single in-order stream; under hipGraph capture the
     // event waits fork the aux streams into the capture and the decode join brings them back)
-    const bool multi = h->n_streams > 1 && !h->profiling && nb <= h->streams_max_batch;
+    const bool multi = h->n_streams > 1 && !h->profiling && nb <= h->streams_max_batch && nb >= h->streams_min_batch;
     if (!multi) {
         for (size_t i = 0; i < h->ops.size(); ++i) { const int rc = launch_op(i, h->stream); if (rc) return rc; }
     } else {

@@ -328,7 +328,7 @@ const char* launch_sppf_pools(const float* src, int src_cs, float* dst, int dst_
     if (C & 3) return "sppf: channel count must be a multiple of 4";
     int pc = 0;
     for (int c = 16; c >= 4; c >>= 1)
-        if ((size_t)2 * H * W * c * sizeof(float) <= 48 * 1024) { pc = c; break; }
+        if ((size_t)2 * H * W * c * sizeof(float) <= 64 * 1024) { pc = c; break; }     // 1280x1280: 40x40 map, 4 channels = 51 KB
     while (pc > 4 && (long)B * ((C + pc - 1) / pc) < 256) pc >>= 1;      // small batches: more, narrower blocks (one per CU at least)
     if (!pc) {
         const int c4n = C / 4;
@@ -436,7 +436,7 @@ const char* launch_sppf_pools_f16(const void* src, int src_cs, void* dst, int ds
     if (C & 7) return "sppf(f16): channel count must be a multiple of 8";
     int pc = 0;
     for (int c = 32; c >= 8; c >>= 1)
-        if ((size_t)2 * H * W * c * 2 <= 48 * 1024) { pc = c; break; }
+        if ((size_t)2 * H * W * c * 2 <= 64 * 1024) { pc = c; break; }                 // 1280x1280: 40x40 map, 8 channels = 51 KB
     if (!pc) {
         const int c8n = C / 8;
         const long total = (long)B * H * W * c8n;
