@@ -1,7 +1,8 @@
 """The reference's preprocessing loop (``/root/reference/preprocess.py:5-58``) over a pluggable frame source.
 
-Frame decode stays on the host (north_star).  ``cv2`` is used when importable; otherwise a clip is a ``.npy``
-stack ``[T,H,W,3]`` uint8 BGR next to the listed path (there is no video decoder in the build image).
+Frame decode stays on the host (north_star).  ``cv2`` is used when importable; otherwise a clip is a directory of frame
+images decoded with Pillow, or a ``.npy`` stack ``[T,H,W,3]`` uint8 BGR next to the listed path (there is no video decoder
+in the build image).
 Semantics kept from the reference: the clip counter ``i`` counts EVERY list line, skipped ones included
 (``preprocess.py:19-20``); only labels in ``videos_to_process`` are handled (``:10-13,27-29``); a clip that fails to
 open is reported and skipped (``:33-35``); the frame number is ``CAP_PROP_POS_FRAMES`` read AFTER ``read()``
@@ -49,12 +50,53 @@ class NpyCapture:
         self._frames = None
 
 
+class ImageDirCapture:
+    """cv2.VideoCapture look-alike over a clip stored as a directory of frame images (``<clip>/0001.jpg`` ... -- how the
+    UCF-Crime frame dumps are distributed), decoded on the host with Pillow: JPEG / PNG -> RGB -> BGR uint8, the layout
+    ``cv2.VideoCapture.read()`` hands to ``/root/reference/preprocess.py:38``.  ``source`` is the directory, or the listed
+    video path whose extension-less name is such a directory (``Shoplifting/Shoplifting001_x264.mp4`` ->
+    ``Shoplifting/Shoplifting001_x264/``)."""
+
+    EXTS = (".jpg", ".jpeg", ".png", ".bmp")
+
+    def __init__(self, source: str):
+        self._files: Optional[List[str]] = None
+        self._pos = 0
+        for cand in (source, os.path.splitext(source)[0]):
+            if os.path.isdir(cand):
+                names = sorted(n for n in os.listdir(cand) if n.lower().endswith(self.EXTS))
+                if names:
+                    self._files = [os.path.join(cand, n) for n in names]
+                    break
+
+    def isOpened(self) -> bool:
+        return self._files is not None
+
+    def read(self):
+        if self._files is None or self._pos >= len(self._files):
+            return False, None
+        from PIL import Image
+        with Image.open(self._files[self._pos]) as im:
+            rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
+        self._pos += 1
+        return True, np.ascontiguousarray(rgb[..., ::-1])          # BGR, as cv2 decodes
+
+    def get(self, prop):
+        return float(self._pos) if prop == CAP_PROP_POS_FRAMES else 0.0
+
+    def release(self):
+        self._files = None
+
+
 def open_capture(path: str):
+    """cv2.VideoCapture when OpenCV is importable (mp4 decode as in the reference); otherwise a directory of frame images
+    (Pillow) or an ``.npy`` frame stack next to the listed path."""
     try:
         import cv2  # noqa: WPS433  (optional; absent in the build image)
         return cv2.VideoCapture(path)
     except ImportError:
-        return NpyCapture(path)
+        cap = ImageDirCapture(path)
+        return cap if cap.isOpened() else NpyCapture(path)
 
 
 def run(people_tracker, list_path: str = "./dataset/Anomaly_Train.txt", dataset_root: str = "./dataset/",

@@ -140,3 +140,30 @@ def test_poselift_bridge_layout(tmp_path):
             assert not np.isnan(np.array(person[1])).any()
     per_person = {pid: sorted(f for f, d in data.items() if pid in d) for pid in (3, 7)}
     assert all(len(v) >= 12 for v in per_person.values())          # seq_len 12 windows exist
+
+
+def test_image_directory_capture_decodes_bgr_frames(tmp_path):
+    """the host front-end without OpenCV: a clip as a directory of frame images (Pillow decode), cv2.VideoCapture semantics
+    (preprocess.py:31-44): BGR uint8 frames, 1-based CAP_PROP_POS_FRAMES after read(), False at the end, closed when missing"""
+    from PIL import Image
+    from cvsd_amd import preprocess_driver as P
+    clip = tmp_path / "Shoplifting" / "Shoplifting001_x264"
+    clip.mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    frames = rng.integers(0, 256, size=(3, 24, 32, 3), dtype=np.uint8)            # BGR
+    for k, f in enumerate(frames):
+        Image.fromarray(f[..., ::-1]).save(clip / f"{k + 1:04d}.png")             # PNG is lossless: exact round trip
+    cap = P.open_capture(str(tmp_path / "Shoplifting" / "Shoplifting001_x264.mp4"))
+    assert isinstance(cap, P.ImageDirCapture) and cap.isOpened()
+    for k in range(3):
+        ok, f = cap.read()
+        assert ok and f.dtype == np.uint8 and f.flags["C_CONTIGUOUS"] and cap.get(P.CAP_PROP_POS_FRAMES) == k + 1
+        np.testing.assert_array_equal(f, frames[k])
+    assert cap.read() == (False, None)
+    cap.release()
+    assert not P.open_capture(str(tmp_path / "Shoplifting" / "missing.mp4")).isOpened()
+    jpg = tmp_path / "Shopping" / "Shopping001_x264"
+    jpg.mkdir(parents=True)
+    Image.fromarray(frames[0][..., ::-1]).save(jpg / "0001.jpg", quality=95)
+    ok, f = P.open_capture(str(jpg)).read()
+    assert ok and f.shape == (24, 32, 3)                                          # JPEG: lossy, shape and layout only
