@@ -198,6 +198,8 @@ void mi355_yolo::free_shape() {
 
 mi355_yolo::~mi355_yolo() {
     (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);      // an asynchronous call may still be running on the buffers freed below
+    for (auto st : aux) if (st) (void)hipStreamSynchronize(st);
     free_shape();
     for (auto& c : dconv) { if (c.wpk) (void)hipFree(c.wpk); if (c.bias) (void)hipFree(c.bias); if (c.w_raw) (void)hipFree(c.w_raw); }
     if (lut) (void)hipFree(lut);
