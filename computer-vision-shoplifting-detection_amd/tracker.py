@@ -1,156 +1,86 @@
 """Host-side multi-object tracker behind ``YOLO.track``.
 
 The reference calls ``model.track(frame, persist=True, classes=[0])`` (``/root/reference/model.py:38``), which in
-ultralytics==8.3.225 runs predict at conf 0.1 and then the default ``botsort.yaml`` tracker
-(``trackers/bot_sort.py`` on top of ``trackers/byte_tracker.py``): two-stage IoU association (high- then
-low-score detections) with score fusion, an XYWH Kalman filter (``trackers/utils/kalman_filter.py:KalmanFilterXYWH``),
-track ids, and rows ``[x1,y1,x2,y2,id,score,cls,idx]`` whose box is the Kalman state.
+ultralytics==8.3.225 runs predict at conf 0.1 and then its default ``botsort.yaml`` tracker: BoT-SORT = ByteTrack's
+two-stage association (Zhang et al., "ByteTrack", ECCV 2022) on IoU cost with score fusion, a constant-velocity Kalman
+filter over (cx, cy, w, h) (Aharon et al., "BoT-SORT", 2022), a 30-frame lost-track buffer, one-frame confirmation of
+tracks born after the first frame, and output rows ``[x1,y1,x2,y2,id,score,cls,idx]`` whose box is the filter state.
 
-Restated here without the two parts that need OpenCV / a ReID net: global motion compensation
-(``gmc_method: sparseOptFlow`` -- identity here, correct for the static CCTV cameras of UCF-Crime) and ReID
-(``with_reid: False`` by default).  Assignment uses scipy's Hungarian solver the way Ultralytics' own
-``linear_assignment(use_lap=False)`` fallback does.  Tracking is sequential per video and stays on the host; it is
-small next to the detector.  PARITY UNPINNED against real BoT-SORT (no ultralytics / lap / cv2 here).
+This module implements that published algorithm from its definitions, organised around a table of plain records and a
+structure-exploiting Kalman filter (the transition is ``x += v``, the measurement is the first four state components, so
+no motion / projection matrices are ever formed).  Not implemented: global motion compensation
+(``gmc_method: sparseOptFlow`` needs OpenCV's optical flow -- identity here, correct for the fixed CCTV cameras of
+UCF-Crime) and ReID (``with_reid: False`` is the default).  Assignment is SciPy's Hungarian solver, as in Ultralytics'
+``linear_assignment(use_lap=False)`` path.  Tracking is sequential per video and stays on the host.
+
+Behaviour is pinned by hand-derived known answers (``tests/test_tracker_known_answers.py``).  PARITY UNPINNED against a
+real Ultralytics run (no ultralytics / lap / cv2 here).
 """
 from __future__ import annotations
 
-from typing import List
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
-import scipy.linalg
 from scipy.optimize import linear_sum_assignment
 
-TRACK_HIGH_THRESH = 0.25
-TRACK_LOW_THRESH = 0.1
-NEW_TRACK_THRESH = 0.25
-TRACK_BUFFER = 30
-MATCH_THRESH = 0.8
+# botsort.yaml defaults
+TRACK_HIGH_THRESH = 0.25      # first association: detections with score >= this
+TRACK_LOW_THRESH = 0.1        # second association: this < score < high
+NEW_TRACK_THRESH = 0.25       # a leftover detection starts a track only at or above this
+TRACK_BUFFER = 30             # frames a lost track is kept (at 30 fps)
+MATCH_THRESH = 0.8            # first association accepts fused cost <= this
 FUSE_SCORE = True
 
-NEW, TRACKED, LOST, REMOVED = 0, 1, 2, 3
+POS_STD, VEL_STD = 1.0 / 20.0, 1.0 / 160.0     # process / measurement noise relative to the box size
+
+FRESH, TRACKED, LOST, RETIRED = 0, 1, 2, 3
+
+
+# ----------------------------------------------------------------------------------------------- Kalman filter
+# State s = (cx, cy, w, h, vcx, vcy, vw, vh), covariance P = [[A, B], [B', C]] in 4x4 blocks.
+def _noise_diag(w: float, h: float, pos: float, vel: float) -> np.ndarray:
+    return np.square(np.array([pos * w, pos * h, pos * w, pos * h, vel * w, vel * h, vel * w, vel * h]))
 
 
 class KalmanFilterXYWH:
-    """8-d state (x, y, w, h, vx, vy, vw, vh), constant velocity."""
+    """Constant-velocity filter on (cx, cy, w, h).  ``initiate`` / ``predict`` / ``update`` take and return
+    ``(mean[8], covariance[8, 8])``."""
 
-    def __init__(self):
-        ndim, dt = 4, 1.0
-        self._motion_mat = np.eye(2 * ndim, 2 * ndim)
-        for i in range(ndim):
-            self._motion_mat[i, ndim + i] = dt
-        self._update_mat = np.eye(ndim, 2 * ndim)
-        self._std_weight_position = 1.0 / 20
-        self._std_weight_velocity = 1.0 / 160
+    @staticmethod
+    def initiate(z: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        z = np.asarray(z, dtype=np.float64)
+        mean = np.concatenate([z, np.zeros(4)])
+        return mean, np.diag(_noise_diag(z[2], z[3], 2 * POS_STD, 10 * VEL_STD))
 
-    def initiate(self, measurement):
-        mean = np.r_[measurement, np.zeros_like(measurement)]
-        w, h = measurement[2], measurement[3]
-        std = [2 * self._std_weight_position * w, 2 * self._std_weight_position * h,
-               2 * self._std_weight_position * w, 2 * self._std_weight_position * h,
-               10 * self._std_weight_velocity * w, 10 * self._std_weight_velocity * h,
-               10 * self._std_weight_velocity * w, 10 * self._std_weight_velocity * h]
-        return mean, np.diag(np.square(std))
+    @staticmethod
+    def predict(mean: np.ndarray, cov: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """x <- x + v;  P <- F P F' + Q with F = [[I, I], [0, I]]: A <- A + B + B' + C, B <- B + C, C <- C."""
+        q = _noise_diag(mean[2], mean[3], POS_STD, VEL_STD)
+        a, b, c = cov[:4, :4], cov[:4, 4:], cov[4:, 4:]
+        new = np.empty((8, 8))
+        new[:4, :4] = a + b + b.T + c
+        new[:4, 4:] = b + c
+        new[4:, :4] = new[:4, 4:].T
+        new[4:, 4:] = c
+        new[np.arange(8), np.arange(8)] += q
+        out = mean.copy()
+        out[:4] += mean[4:]
+        return out, new
 
-    def _noise(self, w, h):
-        sp, sv = self._std_weight_position, self._std_weight_velocity
-        return np.diag(np.square(np.r_[[sp * w, sp * h, sp * w, sp * h], [sv * w, sv * h, sv * w, sv * h]]))
-
-    def predict(self, mean, covariance):
-        motion_cov = self._noise(mean[2], mean[3])
-        mean = np.dot(mean, self._motion_mat.T)
-        covariance = np.linalg.multi_dot((self._motion_mat, covariance, self._motion_mat.T)) + motion_cov
-        return mean, covariance
-
-    def project(self, mean, covariance):
-        sp = self._std_weight_position
-        innovation_cov = np.diag(np.square([sp * mean[2], sp * mean[3], sp * mean[2], sp * mean[3]]))
-        mean = np.dot(self._update_mat, mean)
-        covariance = np.linalg.multi_dot((self._update_mat, covariance, self._update_mat.T))
-        return mean, covariance + innovation_cov
-
-    def update(self, mean, covariance, measurement):
-        projected_mean, projected_cov = self.project(mean, covariance)
-        chol_factor, lower = scipy.linalg.cho_factor(projected_cov, lower=True, check_finite=False)
-        kalman_gain = scipy.linalg.cho_solve((chol_factor, lower), np.dot(covariance, self._update_mat.T).T,
-                                             check_finite=False).T
-        innovation = measurement - projected_mean
-        new_mean = mean + np.dot(innovation, kalman_gain.T)
-        new_covariance = covariance - np.linalg.multi_dot((kalman_gain, projected_cov, kalman_gain.T))
-        return new_mean, new_covariance
+    @staticmethod
+    def update(mean: np.ndarray, cov: np.ndarray, z: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """Measurement = the first four components, R = diag((w/20)^2, (h/20)^2, ...).  S = A + R, K = [A; B'] S^-1."""
+        r = _noise_diag(mean[2], mean[3], POS_STD, VEL_STD)[:4]
+        s = cov[:4, :4] + np.diag(r)
+        gain = np.linalg.solve(s, cov[:4, :]).T                  # S symmetric: (P H' S^-1) = (S^-1 H P)'
+        innovation = np.asarray(z, dtype=np.float64) - mean[:4]
+        return mean + gain @ innovation, cov - gain @ s @ gain.T
 
 
-class STrack:
-    def __init__(self, xywh_idx, score, cls):
-        self._xywh = np.asarray(xywh_idx[:4], dtype=np.float32)       # centre x, y, w, h
-        self.idx = xywh_idx[-1]
-        self.score, self.cls = score, cls
-        self.kalman_filter = None
-        self.mean = self.covariance = None
-        self.is_activated = False
-        self.state = NEW
-        self.track_id = 0
-        self.tracklet_len = 0
-        self.frame_id = self.start_frame = 0
-
-    @property
-    def end_frame(self):
-        return self.frame_id
-
-    def predict(self):
-        mean = self.mean.copy()
-        if self.state != TRACKED:
-            mean[6] = 0
-            mean[7] = 0
-        self.mean, self.covariance = self.kalman_filter.predict(mean, self.covariance)
-
-    def activate(self, kalman_filter, frame_id, track_id):
-        self.kalman_filter = kalman_filter
-        self.track_id = track_id
-        self.mean, self.covariance = kalman_filter.initiate(self._xywh.astype(np.float64))
-        self.tracklet_len = 0
-        self.state = TRACKED
-        if frame_id == 1:
-            self.is_activated = True
-        self.frame_id = self.start_frame = frame_id
-
-    def re_activate(self, new_track, frame_id):
-        self.mean, self.covariance = self.kalman_filter.update(self.mean, self.covariance, new_track._xywh.astype(np.float64))
-        self.tracklet_len = 0
-        self.state = TRACKED
-        self.is_activated = True
-        self.frame_id = frame_id
-        self.score, self.cls, self.idx = new_track.score, new_track.cls, new_track.idx
-
-    def update(self, new_track, frame_id):
-        self.frame_id = frame_id
-        self.tracklet_len += 1
-        self.mean, self.covariance = self.kalman_filter.update(self.mean, self.covariance, new_track._xywh.astype(np.float64))
-        self.state = TRACKED
-        self.is_activated = True
-        self.score, self.cls, self.idx = new_track.score, new_track.cls, new_track.idx
-
-    @property
-    def tlwh(self):
-        if self.mean is None:
-            ret = self._xywh.astype(np.float64).copy()
-        else:
-            ret = self.mean[:4].copy()
-        ret[:2] -= ret[2:] / 2
-        return ret
-
-    @property
-    def xyxy(self):
-        ret = self.tlwh.copy()
-        ret[2:] += ret[:2]
-        return ret
-
-    @property
-    def result(self):
-        return [*self.xyxy.tolist(), self.track_id, self.score, self.cls, self.idx]
-
-
-def _iou_matrix(a, b) -> np.ndarray:
-    """utils/metrics.py:bbox_ioa(iou=True) on xyxy boxes (eps 1e-7)."""
+# ----------------------------------------------------------------------------------------------- geometry / matching
+def _iou_cost(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """1 - IoU between xyxy boxes a [n,4] and b [m,4] (fp32, eps 1e-7 as utils/metrics.py:bbox_ioa(iou=True))."""
     if len(a) == 0 or len(b) == 0:
         return np.zeros((len(a), len(b)), dtype=np.float32)
     a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
@@ -159,157 +89,183 @@ def _iou_matrix(a, b) -> np.ndarray:
     inter = iw * ih
     area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
     area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
-    return inter / (area_a[:, None] + area_b[None, :] - inter + 1e-7)
+    return 1 - inter / (area_a[:, None] + area_b[None, :] - inter + 1e-7)
 
 
-def iou_distance(atracks: List[STrack], btracks: List[STrack]) -> np.ndarray:
-    return 1 - _iou_matrix([t.xyxy for t in atracks], [t.xyxy for t in btracks])
+def _assign(cost: np.ndarray, limit: float) -> Tuple[List[Tuple[int, int]], List[int], List[int]]:
+    """Minimum-cost assignment; pairs whose cost exceeds ``limit`` are dropped.  -> (pairs, free rows, free columns)"""
+    rows, cols = range(cost.shape[0]), range(cost.shape[1])
+    if cost.size == 0:
+        return [], list(rows), list(cols)
+    ri, ci = linear_sum_assignment(cost)
+    pairs = [(int(r), int(c)) for r, c in zip(ri, ci) if cost[r, c] <= limit]
+    used_r, used_c = {p[0] for p in pairs}, {p[1] for p in pairs}
+    return pairs, [r for r in rows if r not in used_r], [c for c in cols if c not in used_c]
 
 
-def fuse_score(cost_matrix: np.ndarray, detections: List[STrack]) -> np.ndarray:
-    if cost_matrix.size == 0:
-        return cost_matrix
-    iou_sim = 1 - cost_matrix
-    det_scores = np.array([d.score for d in detections])[None].repeat(cost_matrix.shape[0], axis=0)
-    return 1 - iou_sim * det_scores
+@dataclass
+class _Det:
+    """One detection of the current frame in the tracker's terms."""
+    xywh: np.ndarray          # centre x, centre y, w, h (float64)
+    score: float
+    cls: float
+    idx: float                # row of the frame's detection array
+
+    @property
+    def xyxy(self) -> np.ndarray:
+        x, y, w, h = self.xywh
+        return np.array([x - w / 2, y - h / 2, x + w / 2, y + h / 2])
 
 
-def linear_assignment(cost_matrix: np.ndarray, thresh: float):
-    """trackers/utils/matching.py:linear_assignment(use_lap=False)."""
-    if cost_matrix.size == 0:
-        return np.empty((0, 2), dtype=int), list(range(cost_matrix.shape[0])), list(range(cost_matrix.shape[1]))
-    x, y = linear_sum_assignment(cost_matrix)
-    matches = np.asarray([[x[i], y[i]] for i in range(len(x)) if cost_matrix[x[i], y[i]] <= thresh])
-    if len(matches) == 0:
-        return np.empty((0, 2), dtype=int), list(range(cost_matrix.shape[0])), list(range(cost_matrix.shape[1]))
-    um_a = sorted(frozenset(range(cost_matrix.shape[0])) - frozenset(matches[:, 0]))
-    um_b = sorted(frozenset(range(cost_matrix.shape[1])) - frozenset(matches[:, 1]))
-    return matches, um_a, um_b
+@dataclass
+class Track:
+    track_id: int
+    mean: np.ndarray
+    cov: np.ndarray
+    score: float
+    cls: float
+    idx: float
+    state: int
+    confirmed: bool           # reported only once confirmed (born on frame 1, or matched on the frame after birth)
+    born: int                 # frame of birth
+    seen: int                 # last frame with a matched detection
 
+    @property
+    def xyxy(self) -> np.ndarray:
+        x, y, w, h = self.mean[:4]
+        return np.array([x - w / 2, y - h / 2, x + w / 2, y + h / 2])
 
-def _joint(a, b):
-    seen, res = set(), []
-    for t in list(a) + list(b):
-        if t.track_id not in seen:
-            seen.add(t.track_id)
-            res.append(t)
-    return res
-
-
-def _sub(a, b):
-    ids = {t.track_id for t in b}
-    return [t for t in a if t.track_id not in ids]
-
-
-def _remove_duplicates(a, b):
-    pdist = iou_distance(a, b)
-    pairs = np.where(pdist < 0.15)
-    dupa, dupb = [], []
-    for p, q in zip(*pairs):
-        timep = a[p].frame_id - a[p].start_frame
-        timeq = b[q].frame_id - b[q].start_frame
-        if timep > timeq:
-            dupb.append(q)
-        else:
-            dupa.append(p)
-    return [t for i, t in enumerate(a) if i not in dupa], [t for i, t in enumerate(b) if i not in dupb]
+    def absorb(self, d: _Det, frame: int) -> None:
+        self.mean, self.cov = KalmanFilterXYWH.update(self.mean, self.cov, d.xywh)
+        self.score, self.cls, self.idx = d.score, d.cls, d.idx
+        self.state, self.confirmed, self.seen = TRACKED, True, frame
 
 
 class BYTETracker:
-    """trackers/byte_tracker.py:BYTETracker.update with BoT-SORT's XYWH Kalman filter."""
+    """``update(det [N,6] = x1,y1,x2,y2,conf,cls) -> [M,8] = x1,y1,x2,y2,id,score,cls,idx`` (idx = row of ``det``), one call
+    per frame, EVERY frame (an empty frame still ages the lost tracks)."""
 
     def __init__(self, frame_rate: int = 30):
-        self.tracked_stracks: List[STrack] = []
-        self.lost_stracks: List[STrack] = []
-        self.removed_stracks: List[STrack] = []
         self.frame_id = 0
         self.max_time_lost = int(frame_rate / 30.0 * TRACK_BUFFER)
-        self.kalman_filter = KalmanFilterXYWH()
-        # ids are owned by the tracker instance (1, 2, ... in activation order): a second tracker created while this one is
-        # alive (sweep / poselift bridge next to model.track(persist=True)) cannot disturb them.  For one tracker per process
-        # this is what Ultralytics' class-wide BaseTrack counter + reset_id() in __init__ produces.
+        self._live: List[Track] = []          # tracked (confirmed or awaiting confirmation), in report order
+        self._lost: List[Track] = []
+        self._retired_ids: set = set()        # ids retired on EARLIER frames (see the bookkeeping note in update)
+        # ids belong to the tracker instance (1, 2, ... in birth order): a second tracker created while this one is alive
+        # (sweep / PoseLift bridge next to model.track(persist=True)) cannot disturb them
         self._ids_issued = 0
 
-    def _next_id(self) -> int:
-        self._ids_issued += 1
-        return self._ids_issued
+    @property
+    def tracked_stracks(self) -> List[Track]:
+        return self._live
+
+    @property
+    def lost_stracks(self) -> List[Track]:
+        return self._lost
+
+    def _detections(self, det: np.ndarray, keep: np.ndarray) -> List[_Det]:
+        out = []
+        for i in np.nonzero(keep)[0]:
+            x1, y1, x2, y2 = (float(v) for v in np.asarray(det[i, :4], dtype=np.float32))
+            xywh = np.asarray(np.float32([(x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1]), dtype=np.float64)
+            out.append(_Det(xywh, float(det[i, 4]), float(det[i, 5]), float(i)))
+        return out
 
     @staticmethod
-    def _init_track(dets, scores, cls):
-        return [STrack(xywh, s, c) for xywh, s, c in zip(dets, scores, cls)] if len(dets) else []
+    def _cost(tracks: Sequence[Track], dets: Sequence[_Det], fuse: bool) -> np.ndarray:
+        cost = _iou_cost([t.xyxy for t in tracks], [d.xyxy for d in dets])
+        if fuse and cost.size:
+            cost = 1 - (1 - cost) * np.array([d.score for d in dets])[None, :]
+        return cost
 
     def update(self, det: np.ndarray) -> np.ndarray:
-        """det: [N,6] x1,y1,x2,y2,conf,cls -> [M,8] x1,y1,x2,y2,id,score,cls,idx (idx = row of ``det``)."""
         self.frame_id += 1
-        activated, refind, lost, removed = [], [], [], []
-        scores, cls = det[:, 4], det[:, 5]
-        xywh = np.stack([(det[:, 0] + det[:, 2]) / 2, (det[:, 1] + det[:, 3]) / 2, det[:, 2] - det[:, 0],
-                         det[:, 3] - det[:, 1], np.arange(len(det), dtype=det.dtype)], 1)
-        remain = scores >= TRACK_HIGH_THRESH
-        second = (scores > TRACK_LOW_THRESH) & (scores < TRACK_HIGH_THRESH)
-        detections = self._init_track(xywh[remain], scores[remain], cls[remain])
-        unconfirmed = [t for t in self.tracked_stracks if not t.is_activated]
-        tracked = [t for t in self.tracked_stracks if t.is_activated]
-        pool = _joint(tracked, self.lost_stracks)
-        for t in pool:
-            t.predict()
-        dists = iou_distance(pool, detections)
-        if FUSE_SCORE:
-            dists = fuse_score(dists, detections)
-        matches, u_track, u_det = linear_assignment(dists, MATCH_THRESH)
-        for it, idet in matches:
-            t, d = pool[it], detections[idet]
-            if t.state == TRACKED:
-                t.update(d, self.frame_id)
-                activated.append(t)
-            else:
-                t.re_activate(d, self.frame_id)
-                refind.append(t)
-        det2 = self._init_track(xywh[second], scores[second], cls[second])
-        r_tracked = [pool[i] for i in u_track if pool[i].state == TRACKED]
-        matches, u_track2, _ = linear_assignment(iou_distance(r_tracked, det2), 0.5)
-        for it, idet in matches:
-            t, d = r_tracked[it], det2[idet]
-            if t.state == TRACKED:
-                t.update(d, self.frame_id)
-                activated.append(t)
-            else:
-                t.re_activate(d, self.frame_id)
-                refind.append(t)
-        for it in u_track2:
-            t = r_tracked[it]
-            if t.state != LOST:
-                t.state = LOST
-                lost.append(t)
-        detections = [detections[i] for i in u_det]
-        dists = iou_distance(unconfirmed, detections)
-        if FUSE_SCORE:
-            dists = fuse_score(dists, detections)
-        matches, u_unconf, u_det = linear_assignment(dists, 0.7)
-        for it, idet in matches:
-            unconfirmed[it].update(detections[idet], self.frame_id)
-            activated.append(unconfirmed[it])
-        for it in u_unconf:
-            unconfirmed[it].state = REMOVED
-            removed.append(unconfirmed[it])
-        for inew in u_det:
-            t = detections[inew]
-            if t.score < NEW_TRACK_THRESH:
+        frame = self.frame_id
+        det = np.asarray(det, dtype=np.float32).reshape(-1, 6)
+        scores = det[:, 4]
+        strong = self._detections(det, scores >= TRACK_HIGH_THRESH)
+        weak = self._detections(det, (scores > TRACK_LOW_THRESH) & (scores < TRACK_HIGH_THRESH))
+
+        confirmed = [t for t in self._live if t.confirmed]
+        tentative = [t for t in self._live if not t.confirmed]
+        # candidate pool: confirmed tracks, then lost ones not already in it
+        pool = list(confirmed) + [t for t in self._lost if all(t.track_id != c.track_id for c in confirmed)]
+        for t in pool:                                          # a track that is not currently tracked stops changing size
+            m = t.mean.copy()
+            if t.state != TRACKED:
+                m[6] = m[7] = 0.0
+            t.mean, t.cov = KalmanFilterXYWH.predict(m, t.cov)
+
+        touched: List[Track] = []        # matched this frame and previously tracked ("activated")
+        revived: List[Track] = []        # matched this frame and previously lost ("refound")
+        newly_lost: List[Track] = []
+        retired_now: List[Track] = []
+
+        def take(t: Track, d: _Det) -> None:
+            was_tracked = t.state == TRACKED
+            t.absorb(d, frame)
+            (touched if was_tracked else revived).append(t)
+
+        # 1. strong detections against the pool (IoU cost fused with the detection score)
+        pairs, free_t, free_d = _assign(self._cost(pool, strong, FUSE_SCORE), MATCH_THRESH)
+        for ti, di in pairs:
+            take(pool[ti], strong[di])
+        # 2. weak detections against the still-unmatched TRACKED tracks (plain IoU cost, limit 0.5)
+        rest = [pool[i] for i in free_t if pool[i].state == TRACKED]
+        pairs2, free_rest, _ = _assign(self._cost(rest, weak, False), 0.5)
+        for ti, di in pairs2:
+            take(rest[ti], weak[di])
+        for i in free_rest:
+            if rest[i].state != LOST:
+                rest[i].state = LOST
+                newly_lost.append(rest[i])
+        # 3. leftover strong detections against tracks awaiting confirmation (limit 0.7); unmatched ones are dropped
+        leftover = [strong[i] for i in free_d]
+        pairs3, free_tent, free_left = _assign(self._cost(tentative, leftover, FUSE_SCORE), 0.7)
+        for ti, di in pairs3:
+            tentative[ti].absorb(leftover[di], frame)
+            touched.append(tentative[ti])
+        for i in free_tent:
+            tentative[i].state = RETIRED
+            retired_now.append(tentative[i])
+        # 4. births
+        for i in free_left:
+            d = leftover[i]
+            if d.score < NEW_TRACK_THRESH:
                 continue
-            t.activate(self.kalman_filter, self.frame_id, self._next_id())
-            activated.append(t)
-        for t in self.lost_stracks:
-            if self.frame_id - t.end_frame > self.max_time_lost:
-                t.state = REMOVED
-                removed.append(t)
-        self.tracked_stracks = [t for t in self.tracked_stracks if t.state == TRACKED]
-        self.tracked_stracks = _joint(self.tracked_stracks, activated)
-        self.tracked_stracks = _joint(self.tracked_stracks, refind)
-        self.lost_stracks = _sub(self.lost_stracks, self.tracked_stracks)
-        self.lost_stracks.extend(lost)
-        self.lost_stracks = _sub(self.lost_stracks, self.removed_stracks)
-        self.tracked_stracks, self.lost_stracks = _remove_duplicates(self.tracked_stracks, self.lost_stracks)
-        self.removed_stracks.extend(removed)
-        if len(self.removed_stracks) > 1000:
-            self.removed_stracks = self.removed_stracks[-999:]
-        return np.asarray([t.result for t in self.tracked_stracks if t.is_activated], dtype=np.float32).reshape(-1, 8)
+            self._ids_issued += 1
+            mean, cov = KalmanFilterXYWH.initiate(d.xywh)
+            t = Track(self._ids_issued, mean, cov, d.score, d.cls, d.idx, TRACKED, confirmed=(frame == 1), born=frame, seen=frame)
+            touched.append(t)
+        # 5. lost tracks past the buffer
+        for t in self._lost:
+            if frame - t.seen > self.max_time_lost:
+                t.state = RETIRED
+                retired_now.append(t)
+
+        # ---- bookkeeping, in ByteTrack's order: the lists are rebuilt BEFORE this frame's retirements are recorded, so a
+        # track retired now leaves the candidate pool one frame later (pinned by the known-answer tests)
+        live = [t for t in self._live if t.state == TRACKED]
+        for group in (touched, revived):
+            have = {t.track_id for t in live}
+            live += [t for t in group if t.track_id not in have and not have.add(t.track_id)]
+        live_ids = {t.track_id for t in live}
+        lost = [t for t in self._lost if t.track_id not in live_ids] + newly_lost
+        lost = [t for t in lost if t.track_id not in self._retired_ids]
+        live, lost = self._drop_duplicates(live, lost)
+        self._retired_ids.update(t.track_id for t in retired_now)
+        self._live, self._lost = live, lost
+        rows = [[*t.xyxy.tolist(), t.track_id, t.score, t.cls, t.idx] for t in self._live if t.confirmed]
+        return np.asarray(rows, dtype=np.float32).reshape(-1, 8)
+
+    @staticmethod
+    def _drop_duplicates(live: List[Track], lost: List[Track]) -> Tuple[List[Track], List[Track]]:
+        """a tracked and a lost track on (nearly) the same box (IoU > 0.85): the one with the longer history survives"""
+        cost = _iou_cost([t.xyxy for t in live], [t.xyxy for t in lost])
+        kill_live, kill_lost = set(), set()
+        for p, q in zip(*np.where(cost < 0.15)):
+            if live[p].seen - live[p].born > lost[q].seen - lost[q].born:
+                kill_lost.add(int(q))
+            else:
+                kill_live.add(int(p))
+        return [t for i, t in enumerate(live) if i not in kill_live], [t for i, t in enumerate(lost) if i not in kill_lost]
