@@ -137,4 +137,27 @@ const char* launch_nms(const NmsArgs& a, hipStream_t st);
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+#if defined(__HIPCC__)
+// XCD-aware work order for the (tile, cout group) grids of the conv kernels.  Workgroups are dealt round-robin over the 8 XCDs
+// in dispatch order (x fastest, then y), so the blocks that share one XCD's L2 are b, b + 8, ...  Each of those eight
+// sequences is given a CONTIGUOUS run of the logical order "tile-major, cout group innermost": the groups of one input tile
+// (which stage the same pixels) and then its x neighbour (which shares the halo columns) follow each other on the same L2.
+// Bijective for any grid size; a pure speed choice -- nothing depends on where a block runs.
+#ifndef MI355_XCD_REMAP
+#define MI355_XCD_REMAP 1
+#endif
+__device__ __forceinline__ void xcd_work_item(int& tile, int& cgroup) {
+#if MI355_XCD_REMAP
+    const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy;
+    const unsigned id = blockIdx.y * gx + blockIdx.x;
+    const unsigned q = n >> 3, r = n & 7, x = id & 7;
+    const unsigned logical = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+    tile = (int)(logical / gy);
+    cgroup = (int)(logical - (unsigned)tile * gy);
+#else
+    tile = (int)blockIdx.x; cgroup = (int)blockIdx.y;
+#endif
+}
+#endif
+
 }  // namespace mi355

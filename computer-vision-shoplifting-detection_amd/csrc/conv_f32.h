@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : 1)) void c
     constexpr int TAPS = KS * KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave % WP, wc = wave / WP;
-    int t = blockIdx.x;
+    int t, cgrp0;
+    xcd_work_item(t, cgrp0);
     const int tx = t % a.tiles_x; t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     const int b = t / a.tiles_y;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : 1)) void c
     // (cgroups > 1 only when all of Cin is staged at once): narrow register tiles (acc + tot = 8 * CT * PT registers) at high
     // occupancy, yet the halo tile is fetched once per block for all CT * WC * cgroups cout tiles.
     for (int cg = 0; cg < a.cgroups; ++cg) {
-        const int ct0 = ((blockIdx.y * WC + wc) * a.cgroups + cg) * CT;
+        const int ct0 = ((cgrp0 * WC + wc) * a.cgroups + cg) * CT;
         // canonical accumulation: `acc` is the fma chain of ONE 16-channel block (all taps), started from +0;
         // `tot` is the running sum of the block partials in block order
         f32x4 acc[CT][PT], tot[CT][PT];
@@ -375,13 +376,14 @@ __global__ __launch_bounds__(256) void conv_splitk_f32(ConvKArgs a) {
     static_assert(TAPS == 9, "split-K kernel is written for 3x3 convs");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform by construction: lets the K offsets live in SGPRs
-    int t = blockIdx.x;
+    int t, cgrp0;
+    xcd_work_item(t, cgrp0);
     const int tx = t % a.tiles_x; t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     const int b = t / a.tiles_y;
     const int oy0 = ty * a.TH, ox0 = tx * a.TW;
     const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
-    const int ct0 = blockIdx.y * CT;
+    const int ct0 = cgrp0 * CT;
     const int npix = a.TW * a.TH;
     float* part = lds + a.lds_buf_floats;                       // [cib][CT][PT][64 lanes][4]
     int xoff[PT];
@@ -525,8 +527,10 @@ __global__ __launch_bounds__(256) void conv1x1_stream_f32(ConvKArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4;
     const int total = a.Wout;                                        // flattened pixels (Hout == 1)
-    const int tile0 = ((int)blockIdx.x * 4 + wave) * PT;             // first 16-pixel tile of this wave
-    const int ct0 = (int)blockIdx.y * CT;
+    int pblk, cgrp0;
+    xcd_work_item(pblk, cgrp0);
+    const int tile0 = (pblk * 4 + wave) * PT;                        // first 16-pixel tile of this wave
+    const int ct0 = cgrp0 * CT;
     const float* xbase[PT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {

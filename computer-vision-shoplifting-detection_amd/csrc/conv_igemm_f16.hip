@@ -110,13 +110,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(ConvKArgs a) {
     constexpr int TAPS = KS * KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave % WP, wc = wave / WP;
-    int t = blockIdx.x;
+    int t, cgrp0;
+    xcd_work_item(t, cgrp0);
     const int tx = t % a.tiles_x; t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     const int b = t / a.tiles_y;
     const int oy0 = ty * a.TH, ox0 = tx * a.TW;
     const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
-    const int ct0 = (blockIdx.y * WC + wc) * CT;
+    const int ct0 = (cgrp0 * WC + wc) * CT;
     const int npix = a.TW * a.TH;
     int xoff[PT];
     size_t po[PT]; bool ok[PT];
@@ -283,8 +284,10 @@ __global__ __launch_bounds__(256) void conv1x1_stream_f16(ConvKArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4;
     const int total = a.Wout;                                        // flattened pixels (Hout == 1)
-    const int tile0 = ((int)blockIdx.x * 4 + wave) * PT;
-    const int ct0 = (int)blockIdx.y * CT;
+    int pblk, cgrp0;
+    xcd_work_item(pblk, cgrp0);
+    const int tile0 = (pblk * 4 + wave) * PT;
+    const int ct0 = cgrp0 * CT;
     const _Float16* xbase[PT];
     size_t po[PT]; bool ok[PT];
 #pragma unroll

@@ -292,6 +292,10 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
             per_cu = std::max(1, std::min(3, (int)((size_t)(160 * 1024) / std::max<size_t>(p.lds, 1))));
         }
         out->grid_x = std::min(out->grid_x, (unsigned)std::max(1, 256 * per_cu / gy));
+        // workgroups are dealt round-robin over the 8 XCDs in dispatch order (x fastest): with grid.x a multiple of 8 the
+        // gy cout groups of one tile column run on the same XCD and stage the same pixels through one L2
+        static const int gx8 = env_int("MI355_PIPE_GX8", 1);
+        if (gx8 && gy > 1 && out->grid_x >= 16) out->grid_x &= ~7u;
     }
     out->grid_y = (unsigned)((a.n_ctiles + p.CT * WC * a.cgroups - 1) / (p.CT * WC * a.cgroups));
     out->lds = p.lds;

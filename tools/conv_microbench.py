@@ -24,7 +24,7 @@ while True:
         break
 print(f"conv {cin}->{cout} k{k} s{s} @{h}x{w} n={n} silu={silu} res={res}: {npl.value} plans")
 srt = sorted(rows)
-for t, d in srt[:10]:
+for t, d in srt[:int(os.environ.get("MB_TOP", "10"))]:
     print(f"  {t*1e3:9.1f} us  {fl/t/1e9:7.1f} TFLOP/s   {d}")
 v2 = [r for r in srt if r[1].startswith("v2")][:6]
 if v2:
