@@ -36,20 +36,19 @@ __device__ __forceinline__ int tile_cout0(int ctile, int g, bool pairs) {
     return pairs ? ((ctile >> 1) * 32 + 8 * g + 4 * (ctile & 1)) : (ctile * 16 + 4 * g);
 }
 
-// bias + SiLU (+ residual) in fp32, one rounding to fp16 (or a plain fp32 store for the head outputs)
+// bias + SiLU (+ residual) in fp32, one rounding to fp16 (or a plain fp32 store for the head outputs).  One 16x16 tile (or
+// one pair of tiles) at a time, accumulator registers -> store: the 128 accumulators of a 128x64 wave tile never sit in
+// arch VGPRs together.
 template <int PT, int CT>
 __device__ __forceinline__ void store_tiles_f16(const ConvKArgs& a, f32x4 (&acc)[CT][PT], const f32x4 (&bias4)[CT], int lane,
                                                 int ct0, const size_t (&po)[PT], const bool (&ok)[PT]) {
     const bool pairs = conv_f16_pairs(a.Cout);
     const int g = lane >> 4;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            f32x4 v = acc[ct][pt] + bias4[ct];
-            if (a.act) { v[0] = fast_silu(v[0]); v[1] = fast_silu(v[1]); v[2] = fast_silu(v[2]); v[3] = fast_silu(v[3]); }
-            acc[ct][pt] = v;
-        }
+    auto act = [&](f32x4 v, const f32x4& bias) {
+        v += bias;
+        if (a.act) { v[0] = fast_silu(v[0]); v[1] = fast_silu(v[1]); v[2] = fast_silu(v[2]); v[3] = fast_silu(v[3]); }
+        return v;
+    };
     if (!a.out_f32 && pairs && (CT % 2 == 0)) {
         // ct0 is even (a multiple of CT): tiles (ct, ct+1) are a pair -> 8 consecutive couts per lane, one 16-byte store
 #pragma unroll
@@ -58,7 +57,7 @@ __device__ __forceinline__ void store_tiles_f16(const ConvKArgs& a, f32x4 (&acc)
             for (int ct = 0; ct < CT; ct += 2) {
                 const int c = tile_cout0(ct0 + ct, g, true);
                 if (!ok[pt] || c >= a.Cout) continue;
-                f32x4 v0 = acc[ct][pt], v1 = acc[ct + 1][pt];
+                f32x4 v0 = act(acc[ct][pt], bias4[ct]), v1 = act(acc[ct + 1][pt], bias4[ct + 1]);
                 if (a.res) {
                     const f16x8 rv = *(const f16x8*)((const _Float16*)a.res + po[pt] * a.res_cs + c);
 #pragma unroll
@@ -77,7 +76,7 @@ __device__ __forceinline__ void store_tiles_f16(const ConvKArgs& a, f32x4 (&acc)
         for (int ct = 0; ct < CT; ++ct) {
             const int c = tile_cout0(ct0 + ct, g, pairs);
             if (!ok[pt] || c >= a.Cout) continue;
-            f32x4 v = acc[ct][pt];
+            f32x4 v = act(acc[ct][pt], bias4[ct]);
             if (a.out_f32) {
                 float* d = a.dst + po[pt] * a.dst_cs + c;
                 if (c + 3 < a.Cout) {
@@ -104,7 +103,7 @@ __device__ __forceinline__ void store_tiles_f16(const ConvKArgs& a, f32x4 (&acc)
 // Block = 256 threads = 4 waves, WP along pixels x WC along couts; a wave owns PT pixel tiles x CT cout tiles of 16x16.
 // The halo tile is staged through LDS in chunks of a.ck channels (a.ck halfs, pixel stride a.ldp = ck + 8 halfs).
 template <int KS, int STRIDE, int PT, int CT, int WP>
-__global__ __launch_bounds__(256) void conv_igemm_f16(ConvKArgs a) {
+__global__ __launch_bounds__(256, (PT == 8 ? 2 : 1)) void conv_igemm_f16(ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds_h[];
     constexpr int WC = 4 / WP;
     constexpr int TAPS = KS * KS;
@@ -120,7 +119,6 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(ConvKArgs a) {
     const int ct0 = (cgrp0 * WC + wc) * CT;
     const int npix = a.TW * a.TH;
     int xoff[PT];
-    size_t po[PT]; bool ok[PT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int p = (wp * PT + pt) * 16 + (lane & 15);
@@ -128,9 +126,6 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(ConvKArgs a) {
         const int ly = (int)(((float)pp + 0.5f) * a.inv_TW);
         const int lx = pp - ly * a.TW;
         xoff[pt] = ((ly * STRIDE) * a.TWin + lx * STRIDE) * a.ldp + (lane >> 4) * 8;
-        const int oy = oy0 + ly, ox = ox0 + lx;
-        ok[pt] = (p < npix) && (oy < a.Hout) && (ox < a.Wout);
-        po[pt] = ((size_t)b * a.Hout + oy) * a.Wout + ox;
     }
     f32x4 acc[CT][PT];
 #pragma unroll
@@ -141,12 +136,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(ConvKArgs a) {
     const _Float16* srcb = (const _Float16*)a.src + (size_t)b * a.Hin * a.Win * a.src_cs;
     const _Float16* zeros = (const _Float16*)a.zeros;
     const _Float16* wbase[CT];
-    f32x4 bias4[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);   // padded cout tiles re-read the last one
         wbase[ct] = (const _Float16*)a.wpk + (size_t)ctile * TAPS * a.cib * 512 + lane * 8;
-        bias4[ct] = *(const f32x4*)(a.bias + tile_cout0(ctile, lane >> 4, conv_f16_pairs(a.Cout)));
     }
     const int ck8m = (a.ck >> 3) - 1;
     const int total_v = a.npix_in << a.ck4_shift;          // 16-byte slots of one staged chunk
@@ -215,7 +208,48 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(ConvKArgs a) {
                 for (int pt = 0; pt < PT; ++pt)
                     acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ct], x[pt], acc[ct][pt], 0, 0, 0);
         };
-        if constexpr (TAPS > 1) {
+        if constexpr (TAPS > 1 && PT == 8) {
+            // 128-pixel wave tiles (128 x CT*16 outputs): the pixel fragments STREAM through a ring of XR registers sets, XD pixel
+            // tiles ahead of the MFMAs that consume them, instead of a whole step's PT fragments being resident -- 16 VGPRs for
+            // the pixel operand instead of 96, which is what lets CT = 3 / 4 (96 / 128 accumulator registers) run at two waves
+            // per SIMD.  Per MFMA this wave tile asks LDS for 1 KiB / CT and L1 for 1 KiB / 8: at CT = 4 half of what
+            // 64 x 64 tiles need from either.
+            static_assert(TAPS % R == 0, "ring slots must line up across k-blocks");
+            constexpr int XR = 4, XD = 2;
+            static_assert(PT % XR == 0 && XD < XR, "ring slots must line up across steps");
+            int xt[TAPS], wt[TAPS];
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) { xt[t] = ((t / KS) * a.TWin + (t % KS)) * a.ldp; wt[t] = t * wstep; }
+            f16x8 xr[XR];
+            auto load_x1 = [&](int slot, int pt, int off) {
+                xr[slot] = *(const f16x8*)__builtin_assume_aligned(lds_h + xoff[pt] + off, 16);
+            };
+            load_w(wf[0], cib0 * 512 + wt[0]);
+            load_w(wf[1], cib0 * 512 + wt[1]);
+#pragma unroll
+            for (int pt = 0; pt < XD; ++pt) load_x1(pt, pt, xt[0]);
+            for (int kb = 0; kb < nkk; ++kb) {
+                const int kn = kb < klast ? kb + 1 : klast;
+                const int wk = opaque((cib0 + kb) * 512), wkn = opaque((cib0 + kn) * 512);
+                const int xk = opaque(kb * 32), xkn = opaque(kn * 32);
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int tw = (t + 2) % TAPS, tn = (t + 1) % TAPS;
+                    load_w(wf[(t + 2) % R], opaque(((t + 2) >= TAPS ? wkn : wk) + wt[tw]));
+                    const int cur = opaque(xk + xt[t]), nxt = opaque(((t + 1) >= TAPS ? xkn : xk) + xt[tn]);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) {
+                        const int pf = pt + XD;
+                        load_x1(pf % XR, pf % PT, pf >= PT ? nxt : cur);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t % R][ct], xr[pt % XR], acc[ct][pt], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        } else if constexpr (TAPS > 1) {
             static_assert(TAPS % R == 0, "ring slots must line up across k-blocks");
             int xt[TAPS], wt[TAPS];
 #pragma unroll
@@ -239,6 +273,40 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(ConvKArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+        } else if constexpr (PT == 8) {
+            // pointwise, 128-pixel wave tiles: the streamed-pixel form of the loop above; a step is a k-block, R per trip
+            constexpr int XR = 4, XD = 2;
+            f16x8 xr[XR];
+            auto load_x1 = [&](int slot, int pt, int off) {
+                xr[slot] = *(const f16x8*)__builtin_assume_aligned(lds_h + xoff[pt] + off, 16);
+            };
+            auto koff = [&](int kb) { return kb < klast ? kb : klast; };
+            load_w(wf[0], (cib0 + koff(0)) * 512);
+            load_w(wf[1], (cib0 + koff(1)) * 512);
+#pragma unroll
+            for (int pt = 0; pt < XD; ++pt) load_x1(pt, pt, 0);
+            auto trip = [&](int kb0, auto guarded) {
+#pragma unroll
+                for (int t = 0; t < R; ++t) {
+                    load_w(wf[(t + 2) % R], opaque((cib0 + koff(kb0 + t + 2)) * 512));
+                    const int cur = opaque(koff(kb0 + t) * 32), nxt = opaque(koff(kb0 + t + 1) * 32);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) {
+                        const int pf = pt + XD;
+                        load_x1(pf % XR, pf % PT, pf >= PT ? nxt : cur);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (!decltype(guarded)::value || kb0 + t < nkk) {
+#pragma unroll
+                            for (int ct = 0; ct < CT; ++ct)
+                                acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t % R][ct], xr[pt % XR], acc[ct][pt], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
+            int kb0 = 0;
+            for (; kb0 + R <= nkk; kb0 += R) trip(kb0, std::false_type{});
+            if (kb0 < nkk) trip(kb0, std::true_type{});
         } else {
             // pointwise: a step is a k-block; R k-blocks per trip so that the ring slots are compile-time
             auto koff = [&](int kb) { return kb < klast ? kb : klast; };
@@ -269,6 +337,24 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(ConvKArgs a) {
                 }
             }
         }
+    }
+    // epilogue operands are derived here, not before the K loop: 3 registers per pixel tile and 4 per cout tile less to carry
+    size_t po[PT]; bool ok[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int p = (wp * PT + pt) * 16 + (lane & 15);
+        const int pp = p < npix ? p : 0;
+        const int ly = (int)(((float)pp + 0.5f) * a.inv_TW);
+        const int lx = pp - ly * a.TW;
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        ok[pt] = (p < npix) && (oy < a.Hout) && (ox < a.Wout);
+        po[pt] = ((size_t)b * a.Hout + oy) * a.Wout + ox;
+    }
+    f32x4 bias4[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+        bias4[ct] = *(const f32x4*)(a.bias + tile_cout0(ctile, lane >> 4, conv_f16_pairs(a.Cout)));
     }
     if (exp_flags & 4) {
 #pragma unroll
