@@ -438,7 +438,7 @@ static int build_schedule(mi355_yolo* h) {
 // process) need not repeat it.  The autotuner's CHOICES -- an index into each conv's candidate list -- are kept in a small
 // text file keyed by (model image hash, precision, frames, H, W, planner version); a file whose candidate counts do not
 // match the running planner is ignored.  MI355_PLAN_CACHE=<dir> moves the directory, MI355_PLAN_CACHE=0 turns it off.
-static const char* kPlanVersion = "mi355-plans-r02e";
+static const char* kPlanVersion = "mi355-plans-r02f";
 
 static std::string plan_cache_path(const mi355_yolo* h, int nb, int Hl, int Wl) {
     const char* e = getenv("MI355_PLAN_CACHE");
@@ -454,6 +454,8 @@ static std::string plan_cache_path(const mi355_yolo* h, int nb, int Hl, int Wl) 
     return dir + name;
 }
 
+constexpr int kUpBase = 10000;       // chosen[i] >= kUpBase: the conv reads the upsample kernel's output with plan chosen[i] - kUpBase
+
 static bool load_plan_choices(const mi355_yolo* h, int nb, int Hl, int Wl, const std::vector<int>& n_cands, std::vector<int>* chosen) {
     const std::string path = plan_cache_path(h, nb, Hl, Wl);
     if (path.empty()) return false;
@@ -465,8 +467,10 @@ static bool load_plan_choices(const mi355_yolo* h, int nb, int Hl, int Wl, const
     std::vector<int> got(n_cands.size(), 0);
     for (size_t i = 0; ok && i < n_cands.size(); ++i) {
         int c = 0, nc = 0;
-        // c >= 0: index into the plain list (nc % 1000 entries); c < 0: fused plan -(c + 1) of nc / 1000
-        ok = std::fscanf(f, "%d/%d", &c, &nc) == 2 && nc == n_cands[i] && (c >= 0 ? (c < nc % 1000 || nc == 0) : (-c - 1 < nc / 1000));
+        // nc = plain + 1000 * fused-pointwise + 1000000 * behind-the-upsample-kernel list sizes.  c in [0, 10000): index into the
+        // plain list; c < 0: fused plan -(c + 1); c >= 10000: plan c - 10000 of the list that reads the upsample kernel's output
+        ok = std::fscanf(f, "%d/%d", &c, &nc) == 2 && nc == n_cands[i] &&
+             (c >= kUpBase ? (c - kUpBase < nc / 1000000) : c >= 0 ? (c < nc % 1000 || nc == 0) : (-c - 1 < (nc / 1000) % 1000));
         got[i] = c;
     }
     std::fclose(f);
@@ -525,7 +529,7 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
     // pass 1: the candidate lists (host work only).  A 3x3 conv that may absorb its pointwise consumer (fuse2) gets two lists:
     // the plain one and the fused one; which form runs is decided below, by the stopwatch.
     std::fill(h->skip_op.begin(), h->skip_op.end(), 0);
-    std::vector<std::vector<ConvLaunch>> cands(h->ops.size()), cands_f(h->ops.size());
+    std::vector<std::vector<ConvLaunch>> cands(h->ops.size()), cands_f(h->ops.size()), cands_u(h->ops.size());
     std::vector<int> n_cands(h->ops.size(), 0);
     const size_t top = (size_t)std::max(1, h->autotune);
     for (size_t i = 0; i < h->ops.size(); ++i) {
@@ -554,6 +558,10 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
             const bool shape_ok = h->bufs[u.src_buf].stride_div == 2 * sd_in && (a.Hin % 2) == 0 && (a.Win % 2) == 0 &&
                                   (u.src_c % (16 / h->dbuf_es[o.src_buf])) == 0;
             if (same_prec && shape_ok && plan_conv_candidates(f, &cands[i]) == nullptr && !cands[i].empty()) {
+                // the other form -- upsample kernel, then any pointwise plan on its output -- competes on the stopwatch below
+                static const bool up_tune = !getenv("MI355_UPSAMPLE_TUNE") || atoi(getenv("MI355_UPSAMPLE_TUNE")) != 0;
+                if (!up_tune || plan_conv_candidates(a, &cands_u[i]) != nullptr) cands_u[i].clear();
+                if (cands_u[i].size() > top) cands_u[i].resize(top);
                 a = f;
                 h->fused_away[h->fuse_up[i]] = 1;
             } else {                                    // no v4 plan for this shape: run the upsample kernel after all
@@ -572,7 +580,7 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
         }
         if (cands[i].empty()) KCHK(plan_conv_candidates(a, &cands[i]));
         if (cands[i].size() > top) cands[i].resize(top);
-        n_cands[i] = (int)cands[i].size() + 1000 * (int)cands_f[i].size();
+        n_cands[i] = (int)cands[i].size() + 1000 * (int)cands_f[i].size() + 1000000 * (int)cands_u[i].size();
         h->plans[i] = cands[i][0];
     }
     // pass 2: choices -- this process's memory, then the plan file, then the stopwatch.  chosen[i] >= 0: index into the plain
@@ -581,6 +589,13 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
     bool have = false;
     for (const auto& t : h->tuned) if (t.first == shape_key) { chosen = t.second; have = true; }
     if (!have && h->autotune) have = load_plan_choices(h, nb, Hl, Wl, n_cands, &chosen);
+    auto run_upsample = [&](int ui) -> int {
+        const FileOp& u = h->ops[ui];
+        const int sd_in = h->bufs[u.src_buf].stride_div, dv = h->dbuf_es[u.src_buf] == 2 ? 2 : 1;
+        KCHK(launch_upsample2x(h->view(u.src_buf, u.src_choff), h->dbuf_cs[u.src_buf] / dv, h->view(u.dst_buf, u.dst_choff),
+                               h->dbuf_cs[u.dst_buf] / dv, nb, Hl / sd_in, Wl / sd_in, u.src_c / dv, h->stream));
+        return MI355_OK;
+    };
     auto time_list = [&](const std::vector<ConvLaunch>& list, const char* name, int* best_k, float* best_ms) -> int {
         // Time launch plans on the real buffers (outputs are overwritten by the next real pass; the accumulation order is
         // plan-independent, so the choice cannot change results).
@@ -612,6 +627,24 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
             int k = 0; float ms = 0.f;
             if (cands[i].size() > 1 || !cands_f[i].empty()) { const int rc = time_list(cands[i], name, &k, &ms); if (rc) return rc; }
             chosen[i] = k;
+            if (!cands_u[i].empty()) {
+                // upsample fused into the read side vs upsample kernel + best plan on its output
+                const int ui = h->fuse_up[i];
+                int ku = 0; float msu = 0.f, msk = 1e30f;
+                const int rc = time_list(cands_u[i], name, &ku, &msu); if (rc) return rc;
+                for (int rep = 0; rep < 3; ++rep) {
+                    HIPCHK(hipEventRecord(h->ev0, h->stream));
+                    const int rcu = run_upsample(ui); if (rcu) return rcu;
+                    HIPCHK(hipEventRecord(h->ev1, h->stream));
+                    HIPCHK(hipEventSynchronize(h->ev1));
+                    float t = 0.f;
+                    HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
+                    if (rep > 0) msk = std::min(msk, t);
+                }
+                if (msu + msk < ms) chosen[i] = kUpBase + ku;
+                if (tune_log) fprintf(stderr, "[tune] %s: upsample on read %.1f us vs upsample kernel %.1f + conv %.1f us -> %s\n", name, ms * 1e3,
+                                      msk * 1e3, msu * 1e3, chosen[i] >= kUpBase ? "separate" : "fused");
+            }
             if (!cands_f[i].empty()) {
                 // fused vs separate: best fused launch against best 3x3 + best pointwise launch
                 const int j = h->fuse2[i];
@@ -634,6 +667,9 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
             if (chosen[i] < 0 && (size_t)(-chosen[i] - 1) < cands_f[i].size()) {
                 h->plans[i] = cands_f[i][-chosen[i] - 1];
                 h->skip_op[h->fuse2[i]] = 1;
+            } else if (chosen[i] >= kUpBase && (size_t)(chosen[i] - kUpBase) < cands_u[i].size()) {
+                h->plans[i] = cands_u[i][chosen[i] - kUpBase];
+                h->fused_away[h->fuse_up[i]] = 0;       // the upsample kernel runs; this conv reads its output
             } else if (chosen[i] >= 0 && (size_t)chosen[i] < cands[i].size()) {
                 h->plans[i] = cands[i][chosen[i]];
             }
