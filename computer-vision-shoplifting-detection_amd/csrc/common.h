@@ -27,9 +27,10 @@ struct ConvArgs {
     // `src2`, a map of half the resolution (pixel (y/2, x/2), stride src2_cs), channels >= up_c from `src` as usual --
     // torch.nn.Upsample + Concat + Conv1x1 of the neck without the upsampled tensor ever being written.
     const float* src2 = nullptr; int src2_cs = 0, up_c = 0;
-    // A pointwise conv fused behind this one (3x3 convs, fp32): Cout2 channels from packed weights w2 / bias2 into dst2; this
+    // A pointwise conv fused behind this one (3x3 convs): Cout2 channels from packed weights w2 / bias2 into dst2; this
     // conv's own dst is then not written (its only reader is that 1x1).  f2_cout = 0: no fusion.
     const float* f2_wpk = nullptr; const float* f2_bias = nullptr; float* f2_dst = nullptr; int f2_dst_cs = 0, f2_cout = 0, f2_act = 0;
+    int f2_out_f32 = 0;                // half=True: the fused pointwise conv writes fp32 (head outputs)
 };
 // number of floats pack_conv_weights writes: ceil(cout/16) * k*k * ceil(cin/16) * 256
 size_t packed_weight_floats(int cout, int cin, int k);
@@ -46,6 +47,7 @@ void floats_to_halfs(const float* in, uint16_t* out_bits, size_t n);     // roun
 void halfs_to_floats(const uint16_t* in_bits, float* out, size_t n);
 const void* pick_conv_kernel_f16(int ks, int stride, int CT, int WP, int version, int stream_pt);
 const void* pick_conv_pipe_f16(int CT, int WP, bool single, bool nkk8);
+const void* pick_conv_fused_f16(int stride, int CT, int WP, int PT);       // conv_f16_fused.hip; PT 0 (= 4) or 8
 struct ConvKArgs {
     const float* src; float* dst; const float* res; const float* wpk; const float* bias;
     int src_cs, dst_cs, res_cs;
@@ -58,10 +60,10 @@ struct ConvKArgs {
     const float* zeros;        // >= 16 bytes of zeros: what out-of-image / beyond-Cin slots read (loads stay unconditional)
     int out_f32;               // fp16 kernels: destination (and residual) hold fp32
     const float* src2; int src2_cs, up_c, up_W, up_H;   // fused upsample-on-read (v4): full-resolution W, H of the conv input
-    int lds_buf_floats;        // fp32: float offset of the second LDS region (split-K partials / fused-1x1 image); fp16 -DMI355_F16_DIAG: flags
+    int lds_buf_floats;        // offset of the second LDS region in 4-byte units (split-K partials / fused-1x1 image); fp16 -DMI355_F16_DIAG, unfused: flags
     int cgroups;               // conv_igemm_f32: groups of CT cout tiles a wave walks over one staged input (>= 1)
-    // conv_igemm_f32<..., F2 = true>: the pointwise conv fused behind this one (packed weights, bias, destination slice)
-    const float* w2; const float* bias2; float* dst2; int dst2_cs, Cout2, n_ctiles2, cib2, act2, ldp2;
+    // conv_igemm_f32 / conv_igemm_f16 <..., F2 = true>: the pointwise conv fused behind this one (packed weights, bias, destination slice)
+    const float* w2; const float* bias2; float* dst2; int dst2_cs, Cout2, n_ctiles2, cib2, act2, ldp2, out2_f32;
     int n_tiles_total;         // B * tiles_x * tiles_y (persistent kernels walk tiles blockIdx.x, + gridDim.x, ...)
 };
 // A planned launch: kernel instance, grid, LDS bytes and kernel arguments.  Planning (tile / wave-arrangement

@@ -117,7 +117,9 @@ std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int ci
                     const int THin = (TH - 1) * stride + ks, TWin = (TW - 1) * stride + ks;
                     const int stage_floats = round_up(THin * TWin * (ck + 4), 4);
                     // fused pointwise stage: the first conv's output image [P pixels][f2_cin16 + 4] lives behind the halo tile
-                    const size_t lds = (size_t)stage_floats * 4 + (f2_cin16 ? (size_t)P * (f2_cin16 + 4) * 4 : 0);
+                    // (fp16: [P][round_up(C1, 32) + 8] halfs)
+                    const size_t lds = (size_t)stage_floats * 4 + (!f2_cin16 ? 0 : half ? (size_t)P * (round_up(f2_cin16, 32) + 8) * 2
+                                                                                        : (size_t)P * (f2_cin16 + 4) * 4);
                     if (lds > LDS_HARD) continue;
                     const double infl = waste_c * (double)tiles * P / ((double)W * H);
                     const double halo = (double)THin * TWin / ((double)TH * TW * stride * stride);
@@ -252,7 +254,8 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
         a.Hin = c.Hin; a.Win = c.Win; a.Hout = c.Hout; a.Wout = c.Wout;
     }
     KernelFn fn = half ? (p.version == 4 ? (KernelFn)pick_conv_pipe_f16(p.CT, p.WP, (c.Cin + 1) / 2 <= p.ck, p.ck > 64)
-                                         : (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.version == 3 ? p.buf_floats : p.PT))
+                          : p.f2 ? (KernelFn)pick_conv_fused_f16(c.stride, p.CT, p.WP, p.PT)
+                                 : (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.version == 3 ? p.buf_floats : p.PT))
                        : (p.version == 3 ? pick_f32_stream(p.CT, p.buf_floats)
                           : p.version == 4 ? pick_f32_pipe(p.CT, p.WP, c.Cin <= p.ck, p.ck, p.PT)
                           : p.version == 6 ? pick_f32_splitk(c.stride, p.CT, p.PT)
@@ -264,9 +267,10 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     if (p.f2) {
         a.w2 = c.f2_wpk; a.bias2 = c.f2_bias; a.dst2 = c.f2_dst; a.dst2_cs = c.f2_dst_cs; a.Cout2 = c.f2_cout; a.act2 = c.f2_act;
         a.n_ctiles2 = (c.f2_cout + 15) / 16; a.cib2 = (c.Cout + 15) / 16; a.ldp2 = round_up(c.Cout, 16) + 4;
+        if (half) { a.cib2 = (c.Cout + 31) / 32; a.ldp2 = 32 * a.cib2 + 8; a.out2_f32 = c.f2_out_f32; }
     }
     if (half && p.version == 4) a.lds_buf_floats = 0;
-    if (half && p.version == 1) { static const int ex = env_int("MI355_F16_EXP", 0); a.lds_buf_floats = ex; }
+    if (half && p.version == 1 && !p.f2) { static const int ex = env_int("MI355_F16_EXP", 0); a.lds_buf_floats = ex; }
     a.TW = p.TW; a.TH = p.TH;
     a.tiles_x = (a.Wout + p.TW - 1) / p.TW; a.tiles_y = (a.Hout + p.TH - 1) / p.TH;
     a.TWin = (p.TW - 1) * c.stride + c.k;
@@ -319,18 +323,26 @@ const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out
     const int H = c.k == 1 ? 1 : c.Hout, W = c.k == 1 ? c.B * c.Hout * c.Wout : c.Wout;
     const bool half = c.dtype == 1;
     // H x W = the map one block grid walks: the image for 3x3 convs (`images` of them), batch x space flattened for 1x1
-    if (c.f2_cout && (half || c.k != 3 || c.res || !c.f2_wpk || !c.f2_bias || !c.f2_dst || (c.f2_dst_cs & 3) || ((uintptr_t)c.f2_dst & 15)))
-        return "conv: a fused pointwise stage needs an fp32 3x3 conv without residual and aligned second-stage buffers";
+    if (c.f2_cout) {
+        const bool wide2 = half && !c.f2_out_f32 && conv_f16_pairs(c.f2_cout);      // 16-byte fp16 stores of the second stage
+        const int cs_mask = wide2 ? 7 : 3, ptr_mask = (!half || wide2 || c.f2_out_f32) ? 15 : 7;
+        if (c.k != 3 || c.res || !c.f2_wpk || !c.f2_bias || !c.f2_dst || (c.f2_dst_cs & cs_mask) || ((uintptr_t)c.f2_dst & ptr_mask) ||
+            (half && c.out_f32))
+            return "conv: a fused pointwise stage needs a 3x3 conv without residual and aligned second-stage buffers";
+    }
     const std::vector<Plan> plans = enumerate_plans(H, W, c.k == 1 ? 1 : c.B, (c.Cout + 15) / 16, half ? (c.Cin + 1) / 2 : c.Cin, c.k,
                                                     c.stride, c.zeros != nullptr, half, c.f2_cout ? round_up(c.Cout, 16) : 0);
     if (plans.empty()) return "conv: no launch plan fits in LDS";
     for (const Plan& p : plans) {
         if (c.src2 && p.version != 4) continue;       // upsample-on-read exists in the v4 kernels only
         ConvLaunch l{};
-        if (const char* e = build_launch(c, p, &l)) return e;
+        if (const char* e = build_launch(c, p, &l)) {
+            if (p.f2) continue;                       // the fused form exists for fewer wave shapes than the plain one
+            return e;
+        }
         out->push_back(l);
     }
-    if (out->empty()) return "conv: no launch plan supports the fused upsample";
+    if (out->empty()) return c.f2_cout ? "conv: no fused launch plan for this shape" : "conv: no launch plan supports the fused upsample";
     return nullptr;
 }
 

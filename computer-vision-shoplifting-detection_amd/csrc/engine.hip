@@ -139,7 +139,7 @@ struct mi355_yolo {
     // output only conv op j reads (or -1); fused_away[i] = that upsample is not launched.  Decided when the weights are
     // loaded (program structure) and confirmed per shape (a v4 launch plan must exist), MI355_FUSE_UPSAMPLE=0 disables it.
     std::vector<int> fuse_up; std::vector<char> fused_away;
-    // Conv3x3 -> Conv1x1 fused into one launch (fp32): fuse2[i] = index of the pointwise conv op whose ONLY input is conv op
+    // Conv3x3 -> Conv1x1 fused into one launch: fuse2[i] = index of the pointwise conv op whose ONLY input is conv op
     // i's output slice, which nobody else reads (or -1): the stride-2 convs in front of every C2f / C3 and the last two convs
     // of every head branch.  Decided from the program at load time, confirmed per shape (a fused launch plan must exist);
     // skip_op[j] = the pointwise op j runs inside its producer's launch.  MI355_FUSE_1X1=0 disables it.
@@ -340,7 +340,7 @@ static int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
     }
     h->fuse2.assign(h->ops.size(), -1); h->skip_op.assign(h->ops.size(), 0);
     const char* f2env = getenv("MI355_FUSE_1X1");
-    if (!h->half && (!f2env || atoi(f2env) != 0)) {
+    if (!f2env || atoi(f2env) != 0) {
         for (size_t i = 0; i < h->ops.size(); ++i) {
             const FileOp& p3 = h->ops[i];
             if (p3.type != OP_CONV || h->convs[p3.conv].k != 3 || p3.res_buf >= 0) continue;
@@ -438,7 +438,7 @@ static int build_schedule(mi355_yolo* h) {
 // process) need not repeat it.  The autotuner's CHOICES -- an index into each conv's candidate list -- are kept in a small
 // text file keyed by (model image hash, precision, frames, H, W, planner version); a file whose candidate counts do not
 // match the running planner is ignored.  MI355_PLAN_CACHE=<dir> moves the directory, MI355_PLAN_CACHE=0 turns it off.
-static const char* kPlanVersion = "mi355-plans-r02f";
+static const char* kPlanVersion = "mi355-plans-r02g";
 
 static std::string plan_cache_path(const mi355_yolo* h, int nb, int Hl, int Wl) {
     const char* e = getenv("MI355_PLAN_CACHE");
@@ -575,6 +575,7 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
             ConvArgs f = a;
             f.f2_wpk = h->dconv[o1.conv].wpk; f.f2_bias = h->dconv[o1.conv].bias;
             f.f2_dst = h->view(o1.dst_buf, o1.dst_choff); f.f2_dst_cs = h->dbuf_cs[o1.dst_buf]; f.f2_cout = c1.cout; f.f2_act = c1.act;
+            f.f2_out_f32 = (h->half && h->dbuf_es[o1.dst_buf] == 4) ? 1 : 0;
             if (plan_conv_candidates(f, &cands_f[i]) != nullptr) cands_f[i].clear();
             if (cands_f[i].size() > top) cands_f[i].resize(top);
         }
@@ -1322,46 +1323,82 @@ int mi355_op_conv2d_f16(int device_id, const float* x, int n, int h, int w, int 
                           out_f32 != 0);
 }
 
-// Conv3x3 (+bias+SiLU) -> Conv1x1 (+bias, optional SiLU) as ONE fused launch (conv_igemm_f32<..., F2 = true>): the parity hook of
-// the fused pairs the engine runs (stride-2 conv -> C2f.cv1, head branch [1] -> [2]).
-int mi355_op_conv2d_fused(int device_id, const float* x, int n, int h, int w, int cin, const float* w1_oihw, const float* b1, int c1,
-                          int stride, const float* w2_oihw, const float* b2, int c2, int silu2, float* y, int plan_index, int* n_plans) {
+// Conv3x3 (+bias+SiLU) -> Conv1x1 (+bias, optional SiLU) as ONE fused launch (conv_igemm_f32 / _f16 <..., F2 = true>): the parity
+// hook of the fused pairs the engine runs (stride-2 conv -> C2f.cv1, head branch [1] -> [2]).
+static int op_conv2d_fused_impl(int device_id, const float* x, int n, int h, int w, int cin, const float* w1_oihw, const float* b1, int c1,
+                                int stride, const float* w2_oihw, const float* b2, int c2, int silu2, float* y, int plan_index, int* n_plans,
+                                bool half, bool out_f32) {
     if (!x || !w1_oihw || !b1 || !w2_oihw || !b2 || !y || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || c1 <= 0 || c2 <= 0) return fail(MI355_EINVAL, "bad argument");
     if ((stride != 1 && stride != 2) || (h % stride) || (w % stride)) return fail(MI355_EINVAL, "stride must be 1 or 2 and divide h and w");
     HIPCHK(hipSetDevice(device_id));
     const int ho = h / stride, wo = w / stride;
-    const int cs_in = round_up(cin, 4), cs_out = round_up(c2, 4);
+    const int es_in = half ? 2 : 4, es_out = (half && !out_f32) ? 2 : 4;
+    const int cs_in = round_up(cin, 16 / es_in), cs_out = round_up(c2, 16 / es_out), cs_mid = round_up(c1, 16 / es_in);
     const size_t npi = (size_t)n * h * w, npo = (size_t)n * ho * wo;
     std::vector<float> xin(npi * cs_in, 0.f), yout(npo * cs_out, 0.f);
     for (size_t p = 0; p < npi; ++p) std::memcpy(&xin[p * cs_in], x + p * cin, (size_t)cin * 4);
     DevMem dm; float *d_x, *d_y, *d_w1, *d_b1, *d_w2, *d_b2, *d_z, *d_mid;
     HIPCHK(dm.alloc(&d_z, 256)); HIPCHK(hipMemset(d_z, 0, 256));
-    HIPCHK(dm.alloc(&d_x, xin.size() * 4)); HIPCHK(hipMemcpy(d_x, xin.data(), xin.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(dm.alloc(&d_y, yout.size() * 4)); HIPCHK(hipMemset(d_y, 0, yout.size() * 4));
-    HIPCHK(dm.alloc(&d_mid, npo * round_up(c1, 4) * 4));          // the unfused destination of the first conv: must stay untouched
-    HIPCHK(hipMemset(d_mid, 0, npo * round_up(c1, 4) * 4));
+    HIPCHK(dm.alloc(&d_x, xin.size() * es_in));
+    if (half) {
+        std::vector<uint16_t> hb(xin.size());
+        floats_to_halfs(xin.data(), hb.data(), xin.size());
+        HIPCHK(hipMemcpy(d_x, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(hipMemcpy(d_x, xin.data(), xin.size() * 4, hipMemcpyHostToDevice));
+    }
+    HIPCHK(dm.alloc(&d_y, yout.size() * es_out)); HIPCHK(hipMemset(d_y, 0, yout.size() * es_out));
+    HIPCHK(dm.alloc(&d_mid, npo * cs_mid * es_in));               // the unfused destination of the first conv: must stay untouched
+    HIPCHK(hipMemset(d_mid, 0, npo * cs_mid * es_in));
     auto upload_conv = [&](const float* wt, const float* b, int co, int ci, int k, float** dw, float** db) -> int {
-        std::vector<float> pk(packed_weight_floats(co, ci, k)), bp(round_up(co, 16), 0.f);
-        pack_conv_weights(wt, co, ci, k, pk.data());
+        std::vector<float> bp(round_up(co, 16), 0.f);
         std::memcpy(bp.data(), b, (size_t)co * 4);
-        HIPCHK(dm.alloc(dw, pk.size() * 4)); HIPCHK(hipMemcpy(*dw, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+        if (half) {
+            std::vector<uint16_t> pk(packed_weight_halfs(co, ci, k));
+            pack_conv_weights_f16(wt, co, ci, k, pk.data());
+            HIPCHK(dm.alloc(dw, pk.size() * 2)); HIPCHK(hipMemcpy(*dw, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+        } else {
+            std::vector<float> pk(packed_weight_floats(co, ci, k));
+            pack_conv_weights(wt, co, ci, k, pk.data());
+            HIPCHK(dm.alloc(dw, pk.size() * 4)); HIPCHK(hipMemcpy(*dw, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+        }
         HIPCHK(dm.alloc(db, bp.size() * 4)); HIPCHK(hipMemcpy(*db, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
         return MI355_OK;
     };
     int rc = upload_conv(w1_oihw, b1, c1, cin, 3, &d_w1, &d_b1); if (rc) return rc;
     rc = upload_conv(w2_oihw, b2, c2, c1, 1, &d_w2, &d_b2); if (rc) return rc;
     ConvArgs a{};
-    a.src = d_x; a.src_cs = cs_in; a.dst = d_mid; a.dst_cs = round_up(c1, 4); a.wpk = d_w1; a.bias = d_b1; a.zeros = d_z;
+    a.src = d_x; a.src_cs = cs_in; a.dst = d_mid; a.dst_cs = cs_mid; a.wpk = d_w1; a.bias = d_b1; a.zeros = d_z;
     a.B = n; a.Hin = h; a.Win = w; a.Hout = ho; a.Wout = wo; a.Cin = cin; a.Cout = c1; a.k = 3; a.stride = stride; a.pad = 1; a.act = 1;
+    a.dtype = half ? 1 : 0;
     a.f2_wpk = d_w2; a.f2_bias = d_b2; a.f2_dst = d_y; a.f2_dst_cs = cs_out; a.f2_cout = c2; a.f2_act = silu2 ? 1 : 0;
+    a.f2_out_f32 = (half && out_f32) ? 1 : 0;
     std::vector<ConvLaunch> cands;
     KCHK(plan_conv_candidates(a, &cands));
     if (n_plans) *n_plans = (int)cands.size();
     KCHK(run_conv(cands[(size_t)(plan_index < 0 ? 0 : plan_index) % cands.size()], nullptr));
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(yout.data(), d_y, yout.size() * 4, hipMemcpyDeviceToHost));
+    if (es_out == 4) {
+        HIPCHK(hipMemcpy(yout.data(), d_y, yout.size() * 4, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<uint16_t> hb(yout.size());
+        HIPCHK(hipMemcpy(hb.data(), d_y, hb.size() * 2, hipMemcpyDeviceToHost));
+        halfs_to_floats(hb.data(), yout.data(), hb.size());
+    }
     for (size_t p = 0; p < npo; ++p) std::memcpy(y + p * c2, &yout[p * cs_out], (size_t)c2 * 4);
     return MI355_OK;
+}
+
+int mi355_op_conv2d_fused(int device_id, const float* x, int n, int h, int w, int cin, const float* w1_oihw, const float* b1, int c1,
+                          int stride, const float* w2_oihw, const float* b2, int c2, int silu2, float* y, int plan_index, int* n_plans) {
+    return op_conv2d_fused_impl(device_id, x, n, h, w, cin, w1_oihw, b1, c1, stride, w2_oihw, b2, c2, silu2, y, plan_index, n_plans, false, false);
+}
+
+int mi355_op_conv2d_fused_f16(int device_id, const float* x, int n, int h, int w, int cin, const float* w1_oihw, const float* b1, int c1,
+                              int stride, const float* w2_oihw, const float* b2, int c2, int silu2, float* y, int out_f32, int plan_index,
+                              int* n_plans) {
+    return op_conv2d_fused_impl(device_id, x, n, h, w, cin, w1_oihw, b1, c1, stride, w2_oihw, b2, c2, silu2, y, plan_index, n_plans, true,
+                                out_f32 != 0);
 }
 
 static int bench_conv2d_impl(int device_id, int n, int h, int w, int cin, int cout, int k, int stride, int silu, int residual,

@@ -48,8 +48,9 @@ def conv2d(x_nhwc: np.ndarray, w_oihw: np.ndarray, bias: np.ndarray, stride: int
 
 
 def conv2d_fused(x_nhwc: np.ndarray, w1: np.ndarray, b1: np.ndarray, w2: np.ndarray, b2: np.ndarray, stride: int = 1, silu2: bool = False,
-                 device: int = 0, plan: int = 0, return_n_plans: bool = False):
-    """Conv3x3 + bias + SiLU -> Conv1x1 + bias (+SiLU) as one fused launch: x [N,H,W,Cin] -> [N,H/s,W/s,C2]."""
+                 device: int = 0, plan: int = 0, return_n_plans: bool = False, half: bool = False, out_f32: bool = False):
+    """Conv3x3 + bias + SiLU -> Conv1x1 + bias (+SiLU) as one fused launch: x [N,H,W,Cin] -> [N,H/s,W/s,C2].
+    ``half``: the half=True kernels (see conv2d); ``out_f32``: the pointwise stage writes fp32 (head finals)."""
     x, w1, b1, w2, b2 = _f32(x_nhwc), _f32(w1), _f32(b1), _f32(w2), _f32(b2)
     n, h, wd, cin = x.shape
     c1, c2 = w1.shape[0], w2.shape[0]
@@ -57,6 +58,11 @@ def conv2d_fused(x_nhwc: np.ndarray, w1: np.ndarray, b1: np.ndarray, w2: np.ndar
         raise ValueError("shape mismatch")
     y = np.empty((n, h // stride, wd // stride, c2), dtype=np.float32)
     npl = C.c_int(0)
+    if half:
+        _lib.check(_lib.lib().mi355_op_conv2d_fused_f16(device, x.ctypes.data, n, h, wd, cin, w1.ctypes.data, b1.ctypes.data, c1, stride,
+                                                        w2.ctypes.data, b2.ctypes.data, c2, int(silu2), y.ctypes.data, int(out_f32),
+                                                        int(plan), C.byref(npl)))
+        return (y, npl.value) if return_n_plans else y
     _lib.check(_lib.lib().mi355_op_conv2d_fused(device, x.ctypes.data, n, h, wd, cin, w1.ctypes.data, b1.ctypes.data, c1, stride,
                                                 w2.ctypes.data, b2.ctypes.data, c2, int(silu2), y.ctypes.data, int(plan), C.byref(npl)))
     return (y, npl.value) if return_n_plans else y

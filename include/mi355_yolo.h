@@ -167,6 +167,12 @@ int  mi355_op_conv2d_f16(int device_id, const float* x, int n, int h, int w, int
 int  mi355_op_conv2d_fused(int device_id, const float* x, int n, int h, int w, int cin, const float* w1_oihw, const float* b1,
                            int c1, int stride, const float* w2_oihw, const float* b2, int c2, int silu2, float* y,
                            int plan_index, int* n_plans);
+/* The same fused pair on the half=True path (operands rounded to fp16 on the way in, the intermediate image rounded to fp16 as the
+ * unfused launch would have stored it, fp32 accumulation; out_f32 = 1: y written as fp32, as for the head's final convs): must
+ * equal mi355_op_conv2d_f16 of the 3x3 conv followed by mi355_op_conv2d_f16 of the 1x1, bit for bit, for every plan_index. */
+int  mi355_op_conv2d_fused_f16(int device_id, const float* x, int n, int h, int w, int cin, const float* w1_oihw, const float* b1,
+                               int c1, int stride, const float* w2_oihw, const float* b2, int c2, int silu2, float* y, int out_f32,
+                               int plan_index, int* n_plans);
 /* Device-resident timing of one conv launch plan on random data (diagnostics / tuning): average milliseconds over
  * `iters` back-to-back launches of candidate plan `plan_index`; plan_desc (optional) receives a description. */
 int  mi355_bench_conv2d(int device_id, int n, int h, int w, int cin, int cout, int k, int stride, int silu, int residual,

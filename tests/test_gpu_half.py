@@ -83,6 +83,38 @@ def test_conv_f16_every_plan_against_float64(case):
             np.testing.assert_array_equal(y, first)
 
 
+FUSED_CASES = [
+    # n, h, w, cin, c1, stride, c2, silu2, out_f32
+    (2, 32, 32, 48, 96, 2, 96, True, False),       # YOLOv8m model.1 -> model.2.cv1
+    (1, 24, 40, 96, 192, 2, 192, True, False),     # model.3 -> model.4.cv1
+    (2, 20, 20, 64, 64, 1, 64, False, True),       # head box branch [1] -> [2] (fp32 logits)
+    (1, 16, 24, 192, 192, 1, 80, False, True),     # head class branch: 12 cout tiles in one block, ragged second stage
+    (1, 17, 19, 51, 51, 1, 51, False, True),       # pose keypoint branch: ragged everything, odd image
+    (2, 16, 16, 32, 80, 1, 48, True, False),       # c1 = 80: the LDS image is padded to 96 channels
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_fused_conv3x3_conv1x1_f16_equals_the_two_launches(case):
+    """every fused launch plan == conv3x3 (stored as fp16) followed by conv1x1, bit for bit: the k-block sum is one MFMA and the
+    block order is the same, so fusing moves no rounding"""
+    from cvsd_amd import ops
+    n, h, w, cin, c1, stride, c2, silu2, out_f32 = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    w1 = (rng.standard_normal((c1, cin, 3, 3), dtype=np.float32) / np.sqrt(cin * 9)).astype(np.float32)
+    b1 = rng.standard_normal(c1).astype(np.float32) * 0.1
+    w2 = (rng.standard_normal((c2, c1, 1, 1), dtype=np.float32) / np.sqrt(c1)).astype(np.float32)
+    b2 = rng.standard_normal(c2).astype(np.float32) * 0.1
+    mid = ops.conv2d(x, w1, b1, stride=stride, silu=True, half=True)
+    want = ops.conv2d(mid, w2, b2, stride=1, silu=silu2, half=True, out_f32=out_f32)
+    y0, n_plans = ops.conv2d_fused(x, w1, b1, w2, b2, stride=stride, silu2=silu2, half=True, out_f32=out_f32, return_n_plans=True)
+    assert n_plans >= 1
+    for plan in range(n_plans):
+        y = ops.conv2d_fused(x, w1, b1, w2, b2, stride=stride, silu2=silu2, half=True, out_f32=out_f32, plan=plan)
+        np.testing.assert_array_equal(y.view(np.uint32), want.view(np.uint32), err_msg=f"plan {plan}")
+
+
 def _half_model(name, ckpt, **kw):
     from cvsd_amd import YOLO
     return YOLO.from_state_dict(name, ckpt[1], half=True, **kw)
