@@ -12,7 +12,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ float silu_m(float v) { return det_silu(v); }
+#ifndef MI355_STEM_EXP
+#define MI355_STEM_EXP 0       // what-if builds only (tools/ab_build.sh): 1 no SiLU, 2 no input conversion, 4 no stores, 8 no MFMAs
+#endif
+__device__ __forceinline__ float silu_m(float v) { return (MI355_STEM_EXP & 1) ? v : det_silu(v); }
 // half=True path only (the value is rounded to fp16 next; same formulation as conv_igemm_f16.hip: 1e-7 relative on the
 // hardware transcendental units instead of the 32-instruction bit-exact form)
 __device__ __forceinline__ float silu_fast(float v) {
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void stem_mfma_u8(StemArgs a) {
     // Byte positions are 32-bit offsets from the frame base (`mis` = its misalignment), so the address math is int32.
     const int mis = (int)((uintptr_t)img & 3);
     const int wrow = a.W * 3;
-    for (int base_item = 0; base_item < n_items; base_item += 4 * 256) {
+    for (int base_item = 0; base_item < ((MI355_STEM_EXP & 2) ? 0 : n_items); base_item += 4 * 256) {
         unsigned bytes[4];
         int dd[4], tlo[4], rlo[4], riy[4];
 #pragma unroll
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void stem_mfma_u8(StemArgs a) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
+    for (int s = 0; s < ((MI355_STEM_EXP & 8) ? 0 : NS); ++s) {
         float xb[PT];
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) xb[pt] = tin[base[pt] + koff[s]];
@@ -143,6 +146,7 @@ __global__ __launch_bounds__(256) void stem_mfma_u8(StemArgs a) {
     for (int pt = 0; pt < PT; ++pt) {
         const int oy = oy0 + wave * PT + pt, ox = ox0 + (lane & 15);
         if (oy >= a.Hout || ox >= a.Wout) continue;
+        if ((MI355_STEM_EXP & 4) && acc[0][pt][0] != 12345.678f) continue;
         const size_t po = ((size_t)b * a.Hout + oy) * a.Wout + ox;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
