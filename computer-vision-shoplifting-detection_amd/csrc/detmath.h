@@ -27,11 +27,12 @@ __device__ __forceinline__ float det_expf(float x) {
     return (e * s1) * s2;
 }
 
-// exp for SiLU only: the argument is clamped to [-87.25, 88], where 2^n is a normal float, so one exact scaling replaces
-// det_expf's two half-steps (6 of SiLU's 32 instructions).  Inside that range the bits are det_expf's; outside it the
-// difference vanishes in 1 + e (below 2^-125) or is a quotient of magnitude 1e-37 (v < -88).
+// exp for SiLU only: the argument is clamped to [-87.25, 87], where 2^n is a normal float, so one exact scaling replaces
+// det_expf's two half-steps, and where 1 + e < 2^126, so that 1 / (1 + e) is a normal float too (det_silu's division relies on
+// it).  Inside that range the bits are det_expf's; outside it the difference vanishes in 1 + e (below 2^-125) or is a quotient
+// of magnitude 1e-36 (v < -87).  The clamp is one v_med3_f32 (fminf(fmaxf(x, lo), hi) for every non-NaN x).
 __device__ __forceinline__ float det_expf_silu(float x) {
-    x = __builtin_fminf(__builtin_fmaxf(x, -87.25f), 88.0f);
+    x = __builtin_amdgcn_fmed3f(x, -87.25f, 87.0f);
     const float t = __builtin_fmaf(x, 1.44269504088896341f, 12582912.0f);
     const float n = t - 12582912.0f;
     float r = __builtin_fmaf(n, -0.693145751953125f, x);
@@ -48,7 +49,25 @@ __device__ __forceinline__ float det_expf_silu(float x) {
     return e * __int_as_float(((int)n + 127) << 23);
 }
 
-__device__ __forceinline__ float det_silu(float v) { return v / (1.0f + det_expf_silu(-v)); }
+// v / d, correctly rounded (= the IEEE quotient the oracle's C division gives), for finite v and d in [1, 2^126): the
+// reciprocal-refinement sequence the compiler emits for fp32 division (v_rcp_f32, one Newton step on r, two residual
+// corrections of q) WITHOUT its range scaling and fix-up instructions (v_div_scale x2, v_div_fixup: 3 of 11), which only act on
+// operands outside that range.  The fp32 matrix instructions and the vector ALU share the SIMD's issue cycles (PMC:
+// SQ_VALU_MFMA_COEXEC_CYCLES = 0, time = 32 x MFMAs + 2 x VALU instructions), so every instruction of the epilogue counts.
+// Not IEEE for v = +-inf (NaN instead of +-inf) and v = -0 (+0): an overflowed activation is garbage either way, and a conv
+// output (+0 + partial sums + bias) is never -0.
+__device__ __forceinline__ float det_div_ge1(float v, float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = v * r;
+    float m = __builtin_fmaf(-d, q, v);
+    q = __builtin_fmaf(m, r, q);
+    m = __builtin_fmaf(-d, q, v);
+    return __builtin_fmaf(m, r, q);
+}
+
+__device__ __forceinline__ float det_silu(float v) { return det_div_ge1(v, 1.0f + det_expf_silu(-v)); }
 __device__ __forceinline__ float det_sigmoid(float v) { return 1.0f / (1.0f + det_expf(-v)); }
 
 }  // namespace mi355

@@ -20,7 +20,7 @@
  *   stem      acc = +0; for kh: for kw: for byte channel (B, G, R): acc = fmaf(lut[byte], w[co][2-ch][kh][kw], acc)
  *             with lut[i] = (float)i / 255.0f; y = silu(acc + bias).
  *   exp       det_expf below (Cody-Waite reduction + degree-5 polynomial, fmaf only, no libm);
- *             silu(v) = v / (1 + det_expf_silu(-v)) (range-restricted exp, same bits on [-87.25, 88]); sigmoid(v) = 1 / (1 + det_expf(-v)).
+ *             silu(v) = v / (1 + det_expf_silu(-v)) (range-restricted exp, same bits on [-87.25, 87]; IEEE division); sigmoid(v) = 1 / (1 + det_expf(-v)).
  *   decode    as ultralytics head.py / tal.py, evaluated left to right without contraction (see det_decode).
  * Compile with -ffp-contract=off -mfma: every fused operation is an explicit fmaf().
  */
@@ -52,10 +52,11 @@ float det_expf(float x) {
     return (e * s1) * s2;
 }
 
-/* exp for SiLU only (csrc/detmath.h:det_expf_silu): argument clamped to [-87.25, 88] where 2^n is a normal float, one exact
- * scaling; identical bits to det_expf inside that range. */
+/* exp for SiLU only (csrc/detmath.h:det_expf_silu): argument clamped to [-87.25, 87] where 2^n is a normal float (one exact
+ * scaling) and 1 + e < 2^126 (its reciprocal is a normal float: the GPU's division sequence needs no range scaling there and
+ * returns the IEEE quotient written below); identical bits to det_expf inside that range. */
 static inline float det_expf_silu(float x) {
-    x = fminf(fmaxf(x, -87.25f), 88.0f);
+    x = fminf(fmaxf(x, -87.25f), 87.0f);
     const float t = fmaf(x, 1.44269504088896341f, 12582912.0f);
     const float n = t - 12582912.0f;
     float r = fmaf(n, -0.693145751953125f, x);

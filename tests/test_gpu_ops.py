@@ -121,6 +121,33 @@ def test_fused_conv_pair_equals_the_two_convs_for_every_plan(n, h, w, cin, c1, s
                                       err_msg=f"fused plan {plan} of {n_plans}")
 
 
+def test_silu_epilogue_is_the_oracles_ieee_division_over_a_dense_sweep():
+    """The kernels' SiLU divides with a reciprocal-refinement sequence (detmath.h:det_div_ge1: 8 instructions, no range scaling or
+    fix-up); the oracle divides with C's `/`.  An identity 1x1 conv (weight 1, bias 0) makes the conv epilogue evaluate silu(x)
+    on any x: 4M values -- a dense grid over [-100, 100], the clamp seams, tiny / huge magnitudes, random bit patterns of finite
+    floats -- must give the oracle's bits, i.e. the correctly rounded quotient.  (-0.0 is not in the sweep: a conv output is
+    `(+0 + partial sums) + bias` and cannot be -0; the refinement sequence would return +0 for it.)"""
+    from cvsd_amd import ops
+    from oracle import det
+    rng = np.random.default_rng(7)
+    bits = rng.integers(0, 2 ** 32, 1_500_000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    bits = bits[np.isfinite(bits)]
+    x = np.concatenate([
+        np.linspace(-100.0, 100.0, 2_000_001),
+        np.linspace(-87.5, -86.5, 200_001), np.linspace(86.5, 88.5, 200_001),
+        rng.normal(0, 4, 500_000), rng.normal(0, 1e-3, 100_000), rng.normal(0, 1e4, 100_000),
+        [0.0, 1e-45, -1e-45, 1.1754944e-38, -1.1754944e-38, 3.0e38, -3.0e38, 87.0, -87.0, 87.25, -87.25, 88.0, -88.0],
+        bits.astype(np.float64)]).astype(np.float32)
+    n = (x.size // 1024) * 1024
+    x = np.ascontiguousarray(x[:n])
+    want = np.empty_like(x)
+    det.lib().det_silu_array(x.ctypes.data, want.ctypes.data, x.size)
+    got = ops.conv2d(x.reshape(1, n // 1024, 1024, 1), np.ones((1, 1, 1, 1), np.float32), np.zeros(1, np.float32), stride=1, silu=True)
+    got = got.reshape(-1)
+    bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+    assert bad.size == 0, (bad.size, x[bad[:5]], got[bad[:5]], want[bad[:5]])
+
+
 def test_conv2d_asymmetric_identity():
     """A = I check with an asymmetric operand (catches a transposed MFMA fragment map)."""
     from cvsd_amd import ops
