@@ -1,9 +1,9 @@
 #!/bin/bash
 # A/B of two builds of the library on the GPU box (run via gpurun): product vs libmi355yolo_exp.so (tools/ab_build.sh),
-# each tuning its own launch plans (plan cache off).  Usage: bash tools/ab_suite.sh [extra env for the B side]
+# each tuning its own launch plans (plan cache off).  Usage: [AB_NAME=exp] bash tools/ab_suite.sh [extra env for the B side]
 cd "$GRAFT_REPO_ROOT"
 export MI355_PLAN_CACHE=0
-EXP=$PWD/computer-vision-shoplifting-detection_amd/libmi355yolo_exp.so
+EXP=$PWD/computer-vision-shoplifting-detection_amd/libmi355yolo_${AB_NAME:-exp}.so
 run() { echo "== $*"; env "$@" python bench.py --no-cpu-baseline --no-configs $ARGS 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], 'fps', d['ms_per_step'], 'ms/step', d['roofline']['achieved'], d['roofline']['unit'])"; }
 ARGS="--steps 10 --warmup 3"
 run A=1
