@@ -120,7 +120,13 @@ __global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : 1)) void c
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int WC = 4 / WP;
     constexpr int TAPS = KS * KS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform by construction: with the wave index in an SGPR the cout-tile base, the weight pointers and their per-tap
+    // offsets are scalar arithmetic, and the fragment loads take the (scalar base + lane offset) form -- no vector instruction
+    // per load (the fp32 matrix instructions and the vector ALU share issue cycles: DESIGN.md 3.1)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, 0x7fffffff, 0x00020000);
     const int wp = wave % WP, wc = wave / WP;
     int t, cgrp0;
     xcd_work_item(t, cgrp0);
@@ -161,14 +167,16 @@ __global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : 1)) void c
             for (int pt = 0; pt < PT; ++pt) tot[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // cout tiles beyond the last one re-read the last tile's weights (their outputs are discarded by the epilogue):
         // no branch around the fragment loads, so hipcc keeps a counted s_waitcnt vmcnt(N) and the prefetch stays in flight
-        const float* wbase[CT];
+        // Weight fragments are fetched through a buffer descriptor over the packed weights: voffset = the lane's 16 bytes (one
+        // VGPR for all loads), soffset = (cout tile, tap, block) in bytes (scalar arithmetic) -- no vector instruction per load.
+        int wbase[CT];
         // the bias of this lane's 4 couts per cout tile is fetched now (the load's L2 latency hides under the staging) and
         // not in the epilogue, where it would sit on the block's critical path
         f32x4 bias4[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
-            wbase[ct] = a.wpk + (size_t)ctile * TAPS * a.cib * 256 + lane * 4;
+            wbase[ct] = ctile * TAPS * a.cib * 256;                          // floats from a.wpk, wave-uniform
             bias4[ct] = *(const f32x4*)(a.bias + ctile * 16 + (lane >> 4) * 4);
         }
 
@@ -222,7 +230,8 @@ __global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : 1)) void c
             auto opaque = [](int v) { asm volatile("" : "+s"(v)); return v; };     // keeps a scalar sum out of LICM's hands
             auto load_w = [&](f32x4* w, int off) {
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(wbase[ct] + off);
+                for (int ct = 0; ct < CT; ++ct)
+                    w[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)lane16, (wbase[ct] + off) * 4, 0));
             };
             auto load_x = [&](f32x4* x, int off) {
 #pragma unroll
