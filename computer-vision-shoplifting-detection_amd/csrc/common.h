@@ -48,6 +48,17 @@ void halfs_to_floats(const uint16_t* in_bits, float* out, size_t n);
 const void* pick_conv_kernel_f16(int ks, int stride, int CT, int WP, int version, int stream_pt);
 const void* pick_conv_pipe_f16(int CT, int WP, bool single, bool nkk8);
 const void* pick_conv_fused_f16(int stride, int CT, int WP, int PT);       // conv_f16_fused.hip; PT 0 (= 4) or 8
+// Division of a block-uniform number by a launch constant on the SCALAR unit (tile decomposition of the conv kernels; the
+// compiler's own lowering of an integer division runs on the vector ALU, which the fp32 matrix instructions share):
+// M = ceil(2^40 / d) as (ml, mh); exact for n < 2^24, 1 <= d < 2^16.
+struct FastDiv { unsigned ml, mh; };
+inline FastDiv make_fastdiv(unsigned d) {
+    const unsigned long long M = ((1ull << 40) + d - 1) / d;
+    return FastDiv{(unsigned)M, (unsigned)(M >> 32)};
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned fastdiv(unsigned n, FastDiv f) { return (__umulhi(n, f.ml) + n * f.mh) >> 8; }
+#endif
 struct ConvKArgs {
     const float* src; float* dst; const float* res; const float* wpk; const float* bias;
     int src_cs, dst_cs, res_cs;
@@ -65,6 +76,8 @@ struct ConvKArgs {
     // conv_igemm_f32 / conv_igemm_f16 <..., F2 = true>: the pointwise conv fused behind this one (packed weights, bias, destination slice)
     const float* w2; const float* bias2; float* dst2; int dst2_cs, Cout2, n_ctiles2, cib2, act2, ldp2, out2_f32;
     int n_tiles_total;         // B * tiles_x * tiles_y (persistent kernels walk tiles blockIdx.x, + gridDim.x, ...)
+    FastDiv fd_tx, fd_ty, fd_gy;   // conv_igemm_f32: scalar division by tiles_x, tiles_y, gridDim.y
+    int img_src, img_dst, img_res; // conv_igemm_f32: elements per image of the source / destination / residual slices' buffers (H * W * cs)
 };
 // A planned launch: kernel instance, grid, LDS bytes and kernel arguments.  Planning (tile / wave-arrangement
 // search) is done once per (op, shape) by the engine; run_conv only enqueues.
@@ -148,6 +161,19 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 #ifndef MI355_XCD_REMAP
 #define MI355_XCD_REMAP 1
 #endif
+// the same with the division by gridDim.y on the scalar unit (fd = make_fastdiv(gridDim.y); total blocks < 2^24)
+__device__ __forceinline__ void xcd_work_item(int& tile, int& cgroup, FastDiv fd) {
+#if MI355_XCD_REMAP
+    const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy;
+    const unsigned id = blockIdx.y * gx + blockIdx.x;
+    const unsigned q = n >> 3, r = n & 7, x = id & 7;
+    const unsigned logical = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+    tile = (int)fastdiv(logical, fd);
+    cgroup = (int)(logical - (unsigned)tile * gy);
+#else
+    tile = (int)blockIdx.x; cgroup = (int)blockIdx.y;
+#endif
+}
 __device__ __forceinline__ void xcd_work_item(int& tile, int& cgroup) {
 #if MI355_XCD_REMAP
     const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy;

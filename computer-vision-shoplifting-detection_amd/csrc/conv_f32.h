@@ -56,29 +56,42 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x4 (&acc)[C
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = acc[ct][pt] + bias4[ct];
     }
+    // Stores (and residual loads) go through buffer descriptors over THIS image of the destination / residual slice: the lane
+    // part of the address (pixel, k-group) is one 32-bit offset per pixel tile, the cout tile is the instruction's scalar
+    // offset -- no 64-bit vector arithmetic per store; lanes outside the tile / image get an offset past num_records, which
+    // drops the store (and reads zeros).
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dst + (size_t)b * (size_t)a.img_dst), 0, (int)((unsigned)a.img_dst * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res + (size_t)b * (size_t)a.img_res : a.dst), 0,
+                                                                         a.res ? (int)((unsigned)a.img_res * 4u) : 0, 0x00020000);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int p = (wp * PT + pt) * 16 + (lane & 15);
         const int pp = p < npix ? p : 0;
         const int ly = (int)(((float)pp + 0.5f) * a.inv_TW);
-        const int lx = pp - ly * a.TW;
+        const int lx = pp - __mul24(ly, a.TW);
         const int oy = oy0 + ly, ox = ox0 + lx;
         const bool ok = (p < npix) && (oy < a.Hout) && (ox < a.Wout);
-        const size_t po = ((size_t)b * a.Hout + oy) * a.Wout + ox;
+        const int pix = __mul24(oy, a.Wout) + ox;
+        const unsigned g16 = (unsigned)(lane >> 4) * 16u;
+        const unsigned dvo = ok ? (unsigned)__mul24(pix, a.dst_cs) * 4u + g16 : 0x80000000u;
+        const unsigned rvo = ok ? (unsigned)__mul24(pix, a.res_cs) * 4u + g16 : 0x80000000u;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            const int c = (ct0 + ct) * 16 + (lane >> 4) * 4;
-            if (!ok || c >= a.Cout) continue;
+            const int c0t = (ct0 + ct) * 16;                             // wave-uniform
+            if (c0t >= a.Cout) continue;
             f32x4 v = acc[ct][pt];
-            float* d = a.dst + po * a.dst_cs + c;
-            if (c + 3 < a.Cout) {
-                if (a.res) v += *(const f32x4*)(a.res + po * a.res_cs + c);
-                *(f32x4*)d = v;
-            } else {
-                for (int i = 0; i < 4 && c + i < a.Cout; ++i) {
+            if (c0t + 16 <= a.Cout) {                                    // whole cout tile: 16-byte accesses
+                if (a.res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)rvo, c0t * 4, 0));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), drs, (int)dvo, c0t * 4, 0);
+            } else {                                                     // ragged last tile (Cout % 16 != 0): dword accesses
+                const int c = c0t + (lane >> 4) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool in = c + i < a.Cout;                      // channels beyond Cout: offset past num_records
                     float r = v[i];
-                    if (a.res) r += a.res[po * a.res_cs + c + i];
-                    d[i] = r;
+                    if (a.res) r += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (int)(in ? rvo + 4u * i : 0x80000000u), c0t * 4, 0));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), drs, (int)(in ? dvo + 4u * i : 0x80000000u), c0t * 4, 0);
                 }
             }
         }
@@ -128,11 +141,12 @@ __global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : 1)) void c
     const unsigned lane16 = (unsigned)lane * 16u;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, 0x7fffffff, 0x00020000);
     const int wp = wave % WP, wc = wave / WP;
+    // tile decomposition on the scalar unit (FastDiv), per-lane products as 24-bit multiplies: the prologue's integer
+    // divisions and 32/64-bit multiplies were ~50 slow vector instructions per block
     int t, cgrp0;
-    xcd_work_item(t, cgrp0);
-    const int tx = t % a.tiles_x; t /= a.tiles_x;
-    const int ty = t % a.tiles_y;
-    const int b = t / a.tiles_y;
+    xcd_work_item(t, cgrp0, a.fd_gy);
+    const int tq = (int)fastdiv((unsigned)t, a.fd_tx), tx = t - tq * a.tiles_x;
+    const int b = (int)fastdiv((unsigned)tq, a.fd_ty), ty = tq - b * a.tiles_y;
     const int oy0 = ty * a.TH, ox0 = tx * a.TW;
     const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
     const int npix = a.TW * a.TH;
@@ -142,10 +156,10 @@ __global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : 1)) void c
         int p = (wp * PT + pt) * 16 + (lane & 15);
         p = p < npix ? p : 0;
         const int ly = (int)(((float)p + 0.5f) * a.inv_TW);
-        const int lx = p - ly * a.TW;
-        xoff[pt] = ((ly * STRIDE) * a.TWin + lx * STRIDE) * a.ldp + (lane >> 4) * 4;
+        const int lx = p - __mul24(ly, a.TW);
+        xoff[pt] = __mul24(__mul24(ly * STRIDE, a.TWin) + lx * STRIDE, a.ldp) + (lane >> 4) * 4;
     }
-    const float* srcb = a.src + (size_t)b * a.Hin * a.Win * a.src_cs;
+    const float* srcb = a.src + (size_t)b * (size_t)a.img_src;
     const int ck4m = (a.ck >> 2) - 1;
     const int total_f4 = a.npix_in << a.ck4_shift;
     const int wstep = a.cib * 256;

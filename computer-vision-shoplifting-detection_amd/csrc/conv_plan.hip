@@ -302,6 +302,16 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
         if (gx8 && gy > 1 && out->grid_x >= 16) out->grid_x &= ~7u;
     }
     out->grid_y = (unsigned)((a.n_ctiles + p.CT * WC * a.cgroups - 1) / (p.CT * WC * a.cgroups));
+    if ((unsigned long long)out->grid_x * out->grid_y >= (1u << 24)) return "conv: more than 2^24 blocks in one launch";
+    a.fd_tx = make_fastdiv((unsigned)std::max(1, a.tiles_x)); a.fd_ty = make_fastdiv((unsigned)std::max(1, a.tiles_y));
+    a.fd_gy = make_fastdiv(std::max(1u, out->grid_y));
+    if (!half && (p.version == 1 || p.f2)) {
+        // conv_igemm_f32 addresses one image of each slice with 32-bit byte offsets (a pointwise launch sees the flattened
+        // batch as one image): such a plan is not offered beyond 2^30 elements (the streaming / pipelined kernels remain)
+        const long long e_src = (long long)a.Hin * a.Win * a.src_cs, e_dst = (long long)a.Hout * a.Wout * std::max(a.dst_cs, a.res_cs);
+        if (e_src >= (1ll << 30) || e_dst >= (1ll << 30)) return "conv: image too large for the 32-bit offsets of conv_igemm_f32";
+    }
+    a.img_src = a.Hin * a.Win * a.src_cs; a.img_dst = a.Hout * a.Wout * a.dst_cs; a.img_res = a.Hout * a.Wout * a.res_cs;
     out->lds = p.lds;
     out->a = a;
     out->CT = p.CT; out->WP = p.WP; out->version = p.version;
@@ -333,16 +343,17 @@ const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out
     const std::vector<Plan> plans = enumerate_plans(H, W, c.k == 1 ? 1 : c.B, (c.Cout + 15) / 16, half ? (c.Cin + 1) / 2 : c.Cin, c.k,
                                                     c.stride, c.zeros != nullptr, half, c.f2_cout ? round_up(c.Cout, 16) : 0);
     if (plans.empty()) return "conv: no launch plan fits in LDS";
+    const char* last_err = nullptr;
     for (const Plan& p : plans) {
         if (c.src2 && p.version != 4) continue;       // upsample-on-read exists in the v4 kernels only
         ConvLaunch l{};
-        if (const char* e = build_launch(c, p, &l)) {
-            if (p.f2) continue;                       // the fused form exists for fewer wave shapes than the plain one
-            return e;
+        if (const char* e = build_launch(c, p, &l)) {   // e.g. the fused form exists for fewer wave shapes than the plain one
+            last_err = e;
+            continue;
         }
         out->push_back(l);
     }
-    if (out->empty()) return c.f2_cout ? "conv: no fused launch plan for this shape" : "conv: no launch plan supports the fused upsample";
+    if (out->empty()) return last_err ? last_err : c.f2_cout ? "conv: no fused launch plan for this shape" : "conv: no launch plan supports the fused upsample";
     return nullptr;
 }
 
