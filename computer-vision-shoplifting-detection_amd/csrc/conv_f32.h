@@ -124,12 +124,18 @@ __device__ __forceinline__ void store_tile(f32x4 v, const float* bias, int act, 
 // of the first conv's channels in LDS ([pixel][channel], exactly the image a 1x1 kernel would have staged from HBM), and
 // the same four waves then run the 1x1 from there -- the intermediate tensor is never written to or read from HBM.
 // Values, operation order and therefore bits are those of the two separate launches.
+#ifndef MI355_V1_MINWAVES16
+#define MI355_V1_MINWAVES16 1    // PT*CT >= 15: asking for two waves costs 16 spilled registers and gains nothing (A/B)
+#endif
+#ifndef MI355_V1_MINWAVES8
+#define MI355_V1_MINWAVES8 3     // PT*CT == 8 instances: 168 registers, no spills, three waves per SIMD instead of two (+0.2-0.6 % A/B)
+#endif
 #ifndef MI355_V1_MINWAVES
 #define MI355_V1_MINWAVES 4      // min waves per SIMD asked of the register allocator for the PT*CT == 4 instances (A/B with
                                  // tools/ab_build.sh: 1 -> 4 costs a 12-byte spill outside the loop, buys 2-3 % on the stride-2 layers, 0-1 % elsewhere)
 #endif
 template <int KS, int STRIDE, int PT, int CT, int WP, bool F2 = false>
-__global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : 1)) void conv_igemm_f32(ConvKArgs a) {
+__global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : PT * CT == 8 ? MI355_V1_MINWAVES8 : PT * CT >= 15 ? MI355_V1_MINWAVES16 : 1)) void conv_igemm_f32(ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int WC = 4 / WP;
     constexpr int TAPS = KS * KS;
