@@ -108,11 +108,16 @@ __device__ __forceinline__ void store_tiles_f16(const ConvKArgs& a, f32x4 (&acc)
 // output tile -- bias + SiLU applied and rounded to fp16, i.e. the values the unfused launch would have stored -- goes to LDS
 // as [pixel][channel] (what a 1x1 kernel would have staged from HBM) and the same four waves run the 1x1 from there.
 template <int KS, int STRIDE, int PT, int CT, int WP, bool F2 = false>
-__global__ __launch_bounds__(256, (PT == 8 ? 2 : 1)) void conv_igemm_f16(ConvKArgs a) {
+__global__ __launch_bounds__(256, (PT == 8 ? (CT <= 3 ? 3 : 2) : 1)) void conv_igemm_f16(ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds_h[];
     constexpr int WC = 4 / WP;
     constexpr int TAPS = KS * KS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave index in an SGPR and weight fragments through a buffer descriptor (voffset = the lane's 16 bytes, soffset = (cout tile,
+    // tap, k-block) on the scalar unit): no vector instruction and no 64-bit pointer pair per load (as conv_igemm_f32)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, 0x7fffffff, 0x00020000);
     const int wp = wave % WP, wc = wave / WP;
     int t, cgrp0;
     xcd_work_item(t, cgrp0);
@@ -140,11 +145,11 @@ __global__ __launch_bounds__(256, (PT == 8 ? 2 : 1)) void conv_igemm_f16(ConvKAr
 
     const _Float16* srcb = (const _Float16*)a.src + (size_t)b * a.Hin * a.Win * a.src_cs;
     const _Float16* zeros = (const _Float16*)a.zeros;
-    const _Float16* wbase[CT];
+    int wbase[CT];                                                                   // halfs from a.wpk, wave-uniform
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);   // padded cout tiles re-read the last one
-        wbase[ct] = (const _Float16*)a.wpk + (size_t)ctile * TAPS * a.cib * 512 + lane * 8;
+        wbase[ct] = ctile * TAPS * a.cib * 512;
     }
     const int ck8m = (a.ck >> 3) - 1;
     const int total_v = a.npix_in << a.ck4_shift;          // 16-byte slots of one staged chunk
@@ -199,7 +204,8 @@ __global__ __launch_bounds__(256, (PT == 8 ? 2 : 1)) void conv_igemm_f16(ConvKAr
         auto load_w = [&](f16x8* w, int off) {
             if (exp_flags & 8) return;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f16x8*)(wbase[ct] + off);
+            for (int ct = 0; ct < CT; ++ct)
+                w[ct] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)lane16, (wbase[ct] + off) * 2, 0));
         };
         auto load_x = [&](f16x8* x, int off) {
             if (exp_flags & 16) return;
