@@ -552,26 +552,38 @@ __global__ __launch_bounds__(256) void conv_splitk_f32(ConvKArgs a) {
 // pixels (HBM latency) and weights (L2 latency).  No LDS, no barriers: waves drift apart and overlap each other's
 // epilogues.  Same canonical accumulation order as v1 (per 16-channel block a chain from +0; partials summed in block order).
 template <int PT, int CT>
-__global__ __launch_bounds__(256) void conv1x1_stream_f32(ConvKArgs a) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(256, (PT * CT >= 16 ? 2 : PT * CT >= 8 ? 3 : 1)) void conv1x1_stream_f32(ConvKArgs a) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: tile bases and weight offsets stay scalar
     const int g = lane >> 4;
     const int total = a.Wout;                                        // flattened pixels (Hout == 1)
     int pblk, cgrp0;
     xcd_work_item(pblk, cgrp0);
-    const int tile0 = (pblk * 4 + wave) * PT;                        // first 16-pixel tile of this wave
     const int ct0 = cgrp0 * CT;
-    const float* xbase[PT];
+    // Every access goes through a buffer descriptor (32-bit lane offset + scalar offset, no 64-bit vector arithmetic; the fp32
+    // matrix instructions share issue cycles with the vector ALU): source / destination / residual descriptors start at THIS
+    // block's first pixel and end at the tensor's last one, so pixels beyond the end read zeros and their stores are dropped.
+    constexpr int BP = 4 * PT * 16;                                  // pixels per block
+    const int p0 = pblk * BP, left = total - p0 < BP ? total - p0 : BP;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src + (size_t)p0 * a.src_cs), 0, left * a.src_cs * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dst + (size_t)p0 * a.dst_cs), 0, left * a.dst_cs * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res + (size_t)p0 * a.res_cs : a.dst), 0,
+                                                                         a.res ? left * a.res_cs * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    unsigned xvo[PT];
+    int pl[PT];                                                      // pixel index inside the block
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-        int p = (tile0 + pt) * 16 + (lane & 15);
-        p = p < total ? p : total - 1;                               // clamp: results of padded pixels are never stored
-        xbase[pt] = a.src + (size_t)p * a.src_cs + 4 * g;
+        pl[pt] = (wave * PT + pt) * 16 + (lane & 15);
+        xvo[pt] = (unsigned)(__mul24(pl[pt], a.src_cs) + 4 * g) * 4u;
     }
-    const float* wbase[CT];
+    int wbase[CT];                                                   // floats from a.wpk
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
-        wbase[ct] = a.wpk + (size_t)ctile * a.cib * 256 + lane * 4;
+        wbase[ct] = ctile * a.cib * 256;
     }
     f32x4 acc[CT][PT];                                               // running sum of the 16-channel block partials
 #pragma unroll
@@ -593,13 +605,12 @@ __global__ __launch_bounds__(256) void conv1x1_stream_f32(ConvKArgs a) {
     int l_it = 0;
     auto load = [&](f32x4* w, f32x4* x) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(wbase[ct] + l_it * 256);
+        for (int ct = 0; ct < CT; ++ct)
+            w[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)lane16, (wbase[ct] + l_it * 256) * 4, 0));
         const bool oob = tail_oob && (l_it == n_it - 1);
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            const float* px = oob ? a.zeros : xbase[pt] + l_it * 16;
-            x[pt] = *(const f32x4*)px;
-        }
+        for (int pt = 0; pt < PT; ++pt)
+            x[pt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(oob ? 0x80000000u : xvo[pt]), l_it * 64, 0));
         if (l_it + 1 < n_it) ++l_it;                                 // clamp instead of guarding the loads
     };
     auto mma = [&](const f32x4* w, const f32x4* x) {              // one 16-channel block: chain from +0, partial added to the sum
@@ -627,25 +638,27 @@ __global__ __launch_bounds__(256) void conv1x1_stream_f32(ConvKArgs a) {
     // epilogue (same math as conv_epilogue, flattened pixel index)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-        const int p = (tile0 + pt) * 16 + (lane & 15);
-        const bool ok = p < total;
+        const unsigned dvo = (unsigned)__mul24(pl[pt], a.dst_cs) * 4u + (unsigned)g * 16u;
+        const unsigned rvo = (unsigned)__mul24(pl[pt], a.res_cs) * 4u + (unsigned)g * 16u;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            const int c = (ct0 + ct) * 16 + g * 4;
-            if (!ok || c >= a.Cout) continue;
+            const int c0t = (ct0 + ct) * 16;                             // wave-uniform
+            if (c0t >= a.Cout) continue;
             f32x4 v = acc[ct][pt] + bias4[ct];
             if (a.act) {
                 v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
             }
-            float* d = a.dst + (size_t)p * a.dst_cs + c;
-            if (c + 3 < a.Cout) {
-                if (a.res) v += *(const f32x4*)(a.res + (size_t)p * a.res_cs + c);
-                *(f32x4*)d = v;
-            } else {
-                for (int i = 0; i < 4 && c + i < a.Cout; ++i) {
+            if (c0t + 16 <= a.Cout) {
+                if (a.res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)rvo, c0t * 4, 0));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), drs, (int)dvo, c0t * 4, 0);
+            } else {                                                     // ragged last cout tile: dword accesses
+                const int c = c0t + g * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool in = c + i < a.Cout;
                     float r = v[i];
-                    if (a.res) r += a.res[(size_t)p * a.res_cs + c + i];
-                    d[i] = r;
+                    if (a.res) r += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (int)(in ? rvo + 4u * i : 0x80000000u), c0t * 4, 0));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), drs, (int)(in ? dvo + 4u * i : 0x80000000u), c0t * 4, 0);
                 }
             }
         }
