@@ -673,11 +673,17 @@ __global__ __launch_bounds__(256, (PT * CT >= 16 ? 2 : PT * CT >= 8 ? 3 : 1)) vo
 // the order of issue is what makes this work: the chunk's weight fragments (all of them: a 1x1 chunk has at most 4 k-blocks)
 // are requested BEFORE the prefetch, hence waiting for them never waits for the prefetch.
 // Same canonical accumulation order as v1 (per 16-channel block a chain over step s, k-group g; partials summed in block order): same bits.
+#ifndef MI355_PIPE_MINWAVES
+#define MI355_PIPE_MINWAVES 2      // 3 fits (168 registers) only with 28-41 spilled registers in the loop: no gain (A/B)
+#endif
 template <int PT, int CT, int WP, bool SINGLE, int NKK>   // SINGLE: Cin fits one chunk -> every item ends a tile; NKK: k-blocks per chunk
-__global__ __launch_bounds__(256) void conv1x1_pipe_f32(ConvKArgs a) {
+__global__ __launch_bounds__(256, (CT <= 2 ? (NKK <= 4 ? MI355_PIPE_MINWAVES : 2) : 1)) void conv1x1_pipe_f32(ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int WC = 4 / WP, NV = 8;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: cout-tile base and weight offsets stay scalar
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, 0x7fffffff, 0x00020000);
     const int wp = wave % WP, wc = wave / WP, g = lane >> 4;
     const int ct0 = (blockIdx.y * WC + wc) * CT;
     const int P = a.TW, total = a.Wout;
@@ -727,12 +733,12 @@ __global__ __launch_bounds__(256) void conv1x1_pipe_f32(ConvKArgs a) {
     int xoff[PT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) xoff[pt] = ((wp * PT + pt) * 16 + (lane & 15)) * a.ldp + 4 * g;
-    const float* wbase[CT];
+    int wbase[CT];                                                   // floats from a.wpk, wave-uniform
     f32x4 bias4[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
-        wbase[ct] = a.wpk + (size_t)ctile * a.cib * 256 + lane * 4;
+        wbase[ct] = ctile * a.cib * 256;
         bias4[ct] = *(const f32x4*)(a.bias + ctile * 16 + g * 4);
     }
     f32x4 acc[CT][PT];
@@ -753,7 +759,8 @@ __global__ __launch_bounds__(256) void conv1x1_pipe_f32(ConvKArgs a) {
         for (int kk = 0; kk < NKK; ++kk) {
             const int kb = cib0 + kk < a.cib ? cib0 + kk : a.cib - 1;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) w[kk][ct] = *(const f32x4*)(wbase[ct] + kb * 256);
+            for (int ct = 0; ct < CT; ++ct)
+                w[kk][ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)lane16, (wbase[ct] + kb * 256) * 4, 0));
         }
     };
     load_w(0);
