@@ -351,27 +351,32 @@ __global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : PT * CT ==
         // ---- second stage: the 1x1 conv over the LDS image; wave (wp, wc) keeps its pixel tiles and takes cout tiles
         // wc, wc + WC, ... of the second conv.  Canonical order as everywhere: per 16-channel block a chain from +0.
         const float* y1 = lds + a.lds_buf_floats;
-        int x2off[PT]; size_t po[PT]; bool ok[PT];
+        // addressing as in conv_epilogue: one image of the destination slice behind a buffer descriptor, 32-bit lane offsets
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int img2 = a.Hout * a.Wout * a.dst2_cs;
+        const __amdgpu_buffer_rsrc_t drs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dst2 + (size_t)b * (size_t)img2), 0, (int)((unsigned)img2 * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, 0x7fffffff, 0x00020000);
+        int x2off[PT]; unsigned dvo[PT];
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
             const int p = (wp * PT + pt) * 16 + (lane & 15);
-            x2off[pt] = p * a.ldp2 + (lane >> 4) * 4;
+            x2off[pt] = __mul24(p, a.ldp2) + (lane >> 4) * 4;
             const int pp = p < npix ? p : 0;
             const int ly = (int)(((float)pp + 0.5f) * a.inv_TW);
-            const int lx = pp - ly * a.TW;
+            const int lx = pp - __mul24(ly, a.TW);
             const int oy = oy0 + ly, ox = ox0 + lx;
-            ok[pt] = (p < npix) && (oy < a.Hout) && (ox < a.Wout);
-            po[pt] = ((size_t)b * a.Hout + oy) * a.Wout + ox;
+            const bool ok = (p < npix) && (oy < a.Hout) && (ox < a.Wout);
+            dvo[pt] = ok ? (unsigned)__mul24(__mul24(oy, a.Wout) + ox, a.dst2_cs) * 4u + (unsigned)(lane >> 4) * 16u : 0x80000000u;
         }
         for (int ct2 = wc; ct2 < a.n_ctiles2; ct2 += WC) {
-            const float* wb = a.w2 + (size_t)ct2 * a.cib2 * 256 + lane * 4;
+            const int wb = ct2 * a.cib2 * 256;                           // floats from a.w2, wave-uniform
             f32x4 tot2[PT];
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) tot2[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            f32x4 w_cur = *(const f32x4*)wb;
+            f32x4 w_cur = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs2, (int)lane16, wb * 4, 0));
             for (int cb = 0; cb < a.cib2; ++cb) {
                 const int cn = cb + 1 < a.cib2 ? cb + 1 : cb;
-                const f32x4 w_nxt = *(const f32x4*)(wb + cn * 256);
+                const f32x4 w_nxt = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs2, (int)lane16, (wb + cn * 256) * 4, 0));
                 f32x4 x2[PT], p2[PT];
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt) x2[pt] = *(const f32x4*)__builtin_assume_aligned(y1 + x2off[pt] + cb * 16, 16);
@@ -384,9 +389,23 @@ __global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : PT * CT ==
                 for (int pt = 0; pt < PT; ++pt) tot2[pt] += p2[pt];
                 w_cur = w_nxt;
             }
+            const int c0t = ct2 * 16, c = c0t + (lane >> 4) * 4;
+            const f32x4 bias2 = *(const f32x4*)(a.bias2 + c);            // the bias array is padded to whole cout tiles
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt)
-                store_tile(tot2[pt], a.bias2, a.act2, nullptr, 0, a.dst2, a.dst2_cs, a.Cout2, ct2, lane, po[pt], ok[pt]);
+            for (int pt = 0; pt < PT; ++pt) {
+                f32x4 v = tot2[pt] + bias2;
+                if (a.act2) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                if (c0t + 16 <= a.Cout2) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), drs2, (int)dvo[pt], c0t * 4, 0);
+                } else {                                                 // ragged last cout tile: dword stores
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float r = v[i];                            // (bit_cast of the vector-element lvalue itself reads element 0)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), drs2,
+                                                              (int)(c + i < a.Cout2 ? dvo[pt] + 4u * i : 0x80000000u), c0t * 4, 0);
+                    }
+                }
+            }
         }
     }
 }
