@@ -438,7 +438,7 @@ static int build_schedule(mi355_yolo* h) {
 // process) need not repeat it.  The autotuner's CHOICES -- an index into each conv's candidate list -- are kept in a small
 // text file keyed by (model image hash, precision, frames, H, W, planner version); a file whose candidate counts do not
 // match the running planner is ignored.  MI355_PLAN_CACHE=<dir> moves the directory, MI355_PLAN_CACHE=0 turns it off.
-static const char* kPlanVersion = "mi355-plans-r02g";
+static const char* kPlanVersion = "mi355-plans-r02h";
 
 static std::string plan_cache_path(const mi355_yolo* h, int nb, int Hl, int Wl) {
     const char* e = getenv("MI355_PLAN_CACHE");
