@@ -178,12 +178,153 @@ __global__ __launch_bounds__(256) void stem_mfma_u8(StemArgs a) {
     }
 }
 
+// half=True form of the stem: Ultralytics' half predictor rounds the /255 input AND the stem's weights to fp16 like every other
+// conv's, so the products are exact in fp32 and K = 27 (108) fits ONE (four) v_mfma_f32_16x16x32_f16 per output tile instead of
+// 7 (27) fp32 MFMAs of 32 cycles each.  Same block / tile geometry and input staging as stem_mfma_u8; the LDS tile holds fp16
+// values (table lookup, then one rounding), the B operand of lane (pixel p, k-group g) is the 8 im2col values k = 32 kb + 8 g ..
+// + 7 gathered with eight ds_read_u16; fp32 accumulation, bias + SiLU in fp32, one rounding on the store.
+template <int KS, int CT>
+__global__ __launch_bounds__(256) void stem_mfma_u8_h(StemArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sl[];
+    constexpr int K = KS * KS * 3, KB = (K + 31) / 32, PT = 4;
+    const int TIN = (STEM_TO - 1) * a.stride + KS;
+    const int trow = TIN * 3;                                   // halfs (= source bytes) per tile row
+    float* lut = sl;
+    _Float16* tin = (_Float16*)(sl + 256);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    lut[tid] = a.lut[tid];
+    const int tiles_x = (a.Wout + STEM_TO - 1) / STEM_TO, tiles_y = (a.Hout + STEM_TO - 1) / STEM_TO;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int oy0 = ty * STEM_TO, ox0 = tx * STEM_TO;
+    const int iy0 = oy0 * a.stride - a.pad, ix0 = ox0 * a.stride - a.pad;
+    const uint8_t* img = a.img + (size_t)b * a.H * a.W * 3;
+    // A operand: lane (row r = cout, k-group g) holds W[cout][k = 32 kb + 8 g + j], j = 0..7, rounded to fp16 (zero beyond K / Cout);
+    // byte channel cb (0=B,1=G,2=R) feeds model channel 2-cb (im[..., ::-1]).  koff = LDS offset of k relative to the pixel's base.
+    f16x8 wa[KB][CT];
+    int koff[KB][8];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 32 * kb + 8 * g + j;
+            const int tap = k / 3, cb = k - tap * 3;
+            const int kh = tap / KS, kw = tap - kh * KS;
+            koff[kb][j] = k < K ? (kh * TIN + kw) * 3 + cb : 0;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int co = ct * 16 + (lane & 15);
+                wa[kb][ct][j] = (_Float16)((k < K && co < a.Cout) ? a.w[((size_t)co * 3 + (2 - cb)) * (KS * KS) + tap] : 0.f);
+            }
+        }
+    __syncthreads();                                            // lut visible
+    // ---- input tile: u8 -> (float)i / 255 -> fp16, 0 outside the image (staging as in stem_mfma_u8) ----
+    const int nd = (trow + 6) >> 2;
+    const int n_items = TIN * nd;
+    const int mis = (int)((uintptr_t)img & 3);
+    const int wrow = a.W * 3;
+    for (int base_item = 0; base_item < n_items; base_item += 4 * 256) {
+        unsigned bytes[4];
+        int dd[4], tlo[4], rlo[4], riy[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int item = base_item + u * 256 + tid;
+            const int iy = item / nd, j = item - iy * nd;
+            const int gy = iy0 + iy;
+            const bool rowin = item < n_items && (unsigned)gy < (unsigned)a.H;
+            const int row_lo = (rowin ? gy : 0) * wrow, row_hi = row_lo + wrow;
+            const int tile_lo = row_lo + ix0 * 3;
+            const int d = ((tile_lo + mis) & ~3) - mis + 4 * j;
+            unsigned v = 0;
+            if (rowin) {
+                if (d >= row_lo && d + 4 <= row_hi) {
+                    v = *(const unsigned*)(img + d);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (d + q >= row_lo && d + q < row_hi) v |= (unsigned)img[d + q] << (8 * q);
+                }
+            }
+            bytes[u] = v; dd[u] = d; tlo[u] = tile_lo; riy[u] = item < n_items ? iy : -1;
+            rlo[u] = rowin ? row_lo : 0x3fffffff;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (riy[u] < 0) continue;
+            const int row_hi = rlo[u] + wrow;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ab = dd[u] + q, rel = ab - tlo[u];
+                if (rel >= 0 && rel < trow) {
+                    const bool inimg = ab >= rlo[u] && ab < row_hi;
+                    tin[riy[u] * trow + rel] = (_Float16)(inimg ? lut[(bytes[u] >> (8 * q)) & 255u] : 0.f);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int ly = wave * PT + pt, lx = lane & 15;
+        const _Float16* px = tin + ((ly * a.stride) * TIN + lx * a.stride) * 3;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            f16x8 xb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xb[j] = px[koff[kb][j]];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[kb][ct], xb, acc[ct][pt], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: lane holds couts 16ct + 4g .. +3 of pixel (row 4*wave + pt, column lane & 15); fp16 stores ----
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int oy = oy0 + wave * PT + pt, ox = ox0 + (lane & 15);
+        if (oy >= a.Hout || ox >= a.Wout) continue;
+        const size_t po = ((size_t)b * a.Hout + oy) * a.Wout + ox;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = ct * 16 + 4 * g;
+            if (c >= a.Cout) continue;
+            const f32x4 v = acc[ct][pt];
+            _Float16* dh = (_Float16*)a.dst + po * a.dst_cs + c;
+            if (c + 3 < a.Cout) {
+                f16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (_Float16)silu_fast(v[j] + a.bias[c + j]);
+                *(f16x4*)dh = o;
+            } else {
+                for (int j = 0; j < 4 && c + j < a.Cout; ++j) dh[j] = (_Float16)silu_fast(v[j] + a.bias[c + j]);
+            }
+        }
+    }
+}
+
 template <int KS>
 static bool launch_stem_mfma(const StemArgs& a, unsigned grid, hipStream_t st) {
     const int tin = (STEM_TO - 1) * a.stride + KS;
     const size_t lds = (256 + (size_t)tin * tin * 3) * sizeof(float);
     if (lds > 64 * 1024) return false;
     const int ct = (a.Cout + 15) / 16;
+    static const bool h_stem = !getenv("MI355_STEM_F16") || atoi(getenv("MI355_STEM_F16")) != 0;
+    if (a.out_half && h_stem) {                      // half=True: fp16 operands (the fp32 kernel's LDS size covers the fp16 tile)
+        switch (ct) {
+            case 1: hipLaunchKernelGGL((stem_mfma_u8_h<KS, 1>), dim3(grid), dim3(256), lds, st, a); return true;
+            case 2: hipLaunchKernelGGL((stem_mfma_u8_h<KS, 2>), dim3(grid), dim3(256), lds, st, a); return true;
+            case 3: hipLaunchKernelGGL((stem_mfma_u8_h<KS, 3>), dim3(grid), dim3(256), lds, st, a); return true;
+            case 4: hipLaunchKernelGGL((stem_mfma_u8_h<KS, 4>), dim3(grid), dim3(256), lds, st, a); return true;
+            case 5: hipLaunchKernelGGL((stem_mfma_u8_h<KS, 5>), dim3(grid), dim3(256), lds, st, a); return true;
+            default: return false;
+        }
+    }
     switch (ct) {
         case 1: hipLaunchKernelGGL((stem_mfma_u8<KS, 1>), dim3(grid), dim3(256), lds, st, a); return true;
         case 2: hipLaunchKernelGGL((stem_mfma_u8<KS, 2>), dim3(grid), dim3(256), lds, st, a); return true;

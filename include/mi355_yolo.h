@@ -47,8 +47,8 @@ typedef struct mi355_yolo mi355_yolo;   /* opaque engine handle */
 typedef struct mi355_opts {
     int struct_size;
     int batch_chunk;      /* frames pushed through the net per pass (default 64); larger batches are looped */
-    int half;             /* 1 = Ultralytics' half=True (engine/predictor.py: model.half(), im.half()): activations and
-                           * weights stored as fp16, fp32 accumulate / bias / SiLU, head logits, decode and NMS in fp32.
+    int half;             /* 1 = Ultralytics' half=True (engine/predictor.py: model.half(), im.half()): activations (the /255
+                           * input included) and weights stored as fp16, fp32 accumulate / bias / SiLU, head logits, decode and NMS in fp32.
                            * Results then differ from the fp32 path by fp16 rounding (not a bit-exact mode). */
     int reserved[5];
 } mi355_opts;

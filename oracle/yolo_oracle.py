@@ -72,7 +72,7 @@ class OracleModel:
 
     def __init__(self, name: str, state_dict: Dict[str, np.ndarray], nc: Optional[int] = None, half: bool = False):
         # half: restates the ENGINE's half=True contract (include/mi355_yolo.h, mi355_opts.half), which is what Ultralytics'
-        # half=True predictor does up to where roundings fall: weights of every conv but the u8 stem rounded to fp16,
+        # half=True predictor does up to where roundings fall: weights of every conv (the stem's too) and the /255 input rounded to fp16,
         # every stored activation rounded to fp16 once (after bias + SiLU + residual, all in fp32), the head's final 1x1
         # convs, decode and NMS in fp32.  Ultralytics itself refuses half on CPU, so this mode has no CPU reference run.
         self.half = bool(half)
@@ -98,7 +98,7 @@ class OracleModel:
             b_conv = torch.zeros(w.shape[0])
             b_bn = b - g.mul(mu).div(torch.sqrt(var + eps))
             bf = torch.mm(w_bn, b_conv.reshape(-1, 1)).reshape(-1) + b_bn
-            if self.half and w.shape[1] != 3:            # the stem reads u8 pixels and keeps fp32 weights
+            if self.half:                                # model.half(): every conv's weights, the stem's included
                 wf = wf.half().float()
             self._fused[prefix] = (wf, bf)
         return self._fused[prefix]
@@ -196,6 +196,7 @@ class OracleModel:
     @torch.no_grad()
     def forward(self, x: torch.Tensor, return_features: bool = False):
         ys: List[torch.Tensor] = []
+        x = self._store(x)                               # half: im.half() -- the /255 input is an fp16 tensor too
         for i, (f, n, m, args) in enumerate(self.yaml):
             n = max(round(n * self.depth), 1) if n > 1 else n
             if isinstance(f, int):

@@ -90,8 +90,9 @@ def test_scale_back_and_xywhn():
 
 
 def test_half_storage_mode_of_the_oracle(v8n):
-    """oracle half=True (the engine's half contract): weights of every conv but the stem and every stored activation are
-    fp16 values; the head logits stay fp32; results stay close to fp32; fp32 mode is untouched by the option."""
+    """oracle half=True (the engine's half contract): the weights of every conv (the stem's too: model.half()), the /255 input
+    (im.half()) and every stored activation are fp16 values; the head logits stay fp32; results stay close to fp32; fp32 mode is
+    untouched by the option."""
     import torch
     from oracle import yolo_oracle as O
     from tools import synth
@@ -103,7 +104,7 @@ def test_half_storage_mode_of_the_oracle(v8n):
     assert torch.equal(w16, w16.half().float())                       # fp16-representable weights
     w_stem16, _ = o16._fused_conv("model.0")
     w_stem32, _ = o32._fused_conv("model.0")
-    assert torch.equal(w_stem16, w_stem32)                            # the u8 stem keeps fp32 weights
+    assert torch.equal(w_stem16, w_stem32.half().float()) and not torch.equal(w_stem16, w_stem32)   # the stem's weights are fp16 too
     feats = o16.forward(x, return_features=True)
     for f in feats:
         assert torch.equal(f, f.half().float())                       # stored activations are fp16 values
