@@ -35,13 +35,18 @@ N_BASE_FRAMES = 16              # frames made by tools/synth.py on the host (the
 # BASELINE.json configs 2-5 as stated, per GPU (config 4 shards batch 64 over 8 GPUs: 8 per GPU, and 64 per GPU for the
 # throughput form; config 5 shards batch 16 over 8 GPUs: 2 per GPU, and 16 on one GPU): (model, size, batch, half, steps, warmup)
 EXTRA_CONFIGS = [
-    ("yolov8n", 640, 1, False, 600, 100),
-    ("yolov8n-pose", 640, 32, False, 40, 5),
-    ("yolov8s-pose", 640, 8, False, 60, 8),
-    ("yolov8s-pose", 640, 64, False, 12, 3),
-    ("yolov8m", 1280, 2, True, 40, 5),
-    ("yolov8m", 1280, 16, True, 10, 3),
+    # (model, size, batch, half, steps, warmup, cpu_budget_s): cpu_budget_s = wall-clock budget of the torch-CPU reference
+    # timing at THIS config's batch (0: none -- the batch-64 form of config 4 is 8x the batch-8 entry's CPU work)
+    ("yolov8n", 640, 1, False, 600, 100, 6.0),
+    ("yolov8n-pose", 640, 32, False, 40, 5, 20.0),
+    ("yolov8s-pose", 640, 8, False, 60, 8, 14.0),
+    ("yolov8s-pose", 640, 64, False, 12, 3, 0.0),
+    ("yolov8m", 1280, 2, True, 40, 5, 14.0),
+    ("yolov8m", 1280, 16, True, 10, 3, 0.0),
+    # the reference's literal checkpoint family and call: YOLO("./models/yolov5mu.pt") + .track() = batch 1 (/root/reference/model.py:18,38)
+    ("yolov5mu", 640, 1, False, 300, 50, 8.0),
 ]
+HEADLINE_CPU_BUDGET_S = 18.0
 
 
 def make_frames(n: int, size: int, seed: int):
@@ -88,15 +93,167 @@ def profile_convs(model, frames, size: int, steps: int = 3):
     return conv_ms / steps, launches // steps, kinds
 
 
-def measure_config(model_name: str, size: int, batch: int, half: bool, steps: int, warmup: int) -> dict:
-    """One BASELINE configuration on this GPU: frames resident in HBM, rows returned to the host every step."""
+def _delta_stats(d) -> dict:
+    """|delta| samples -> the figures north_star's accuracy clause is about (1e-3 = its tolerance)."""
+    d = np.asarray(d, dtype=np.float64).ravel()
+    if d.size == 0:
+        return {"n": 0}
+    return {"n": int(d.size), "max": float(f"{d.max():.3e}"), "p999": float(f"{np.quantile(d, 0.999):.3e}"),
+            "mean": float(f"{d.mean():.3e}"), "frac_within_1e-3": round(float((d <= 1e-3).mean()), 5)}
+
+
+def parity_report(model, model_name: str, sd, frames_np, size: int, want=None, f64_frames: int = 2) -> dict:
+    """GPU rows vs the torch-CPU oracle's rows on the same frames (post-NMS, original-image pixels): frames whose kept
+    anchor lists are identical, |delta| of every box / keypoint coordinate on those frames, the fraction within
+    north_star's 1e-3 -- and, side by side, BOTH fp32 implementations against a float64 execution of the same program at
+    the anchors that survive NMS (what 1e-3 means for fp32 at stride 32 is only visible against that yardstick)."""
+    from oracle import yolo_oracle as O
+    from tools import precision as P
+    om = None
+    if want is None:
+        om = O.OracleModel(model_name, sd)
+        want, _ = O.predict(om, list(frames_np), imgsz=size)
+    got = model.predict(frames_np, imgsz=size)
+    same, rows, d_box, d_kpt, cls_equal = 0, 0, [], [], True
+    for g, w in zip(got, want):
+        wa = w["anchor_idx"].numpy()
+        if not np.array_equal(g.anchor_idx, wa):
+            continue
+        same += 1
+        rows += len(wa)
+        if not len(wa):
+            continue
+        gb, wb = g.boxes.data.numpy(), w["boxes"].numpy()
+        cls_equal &= bool(np.array_equal(gb[:, 5], wb[:, 5]))
+        d_box.append(np.abs(gb[:, :4] - wb[:, :4]).ravel())
+        if w["kpts"] is not None:
+            d_kpt.append(np.abs(g.keypoints_raw[..., :2] - w["kpts"].numpy()[..., :2]).ravel())
+    out = {"vs": "oracle/yolo_oracle.py (torch CPU fp32 restatement of the Ultralytics path; parity unpinned against Ultralytics itself)",
+           "frames": len(got), "frames_with_identical_indices": same, "rows_compared": rows, "class_indices_identical": cls_equal,
+           "post_nms_box_abs_err_px": _delta_stats(np.concatenate(d_box) if d_box else [])}
+    if d_kpt:
+        out["post_nms_kpt_abs_err_px"] = _delta_stats(np.concatenate(d_kpt))
+    try:
+        nf = min(f64_frames, len(frames_np))
+        if nf > 0:
+            om = om or O.OracleModel(model_name, sd)
+            ref = P.f64_head(model_name, sd, frames_np[:nf], size)
+            gh = model.raw_head(frames_np[:nf], imgsz=size)
+            th = om.forward(O.preprocess(list(frames_np[:nf]), size)).numpy()
+            sel = [(i, a) for i in range(nf) for a in got[i].anchor_idx.tolist()]
+            if sel:
+                ii, aa = np.array([s_[0] for s_ in sel]), np.array([s_[1] for s_ in sel])
+                pick = lambda t: t[ii, :4, aa].astype(np.float64)
+                out["kept_anchor_box_abs_err_px"] = {"gpu_vs_f64": _delta_stats(np.abs(pick(gh) - pick(ref))),
+                                                     "torch_vs_f64": _delta_stats(np.abs(pick(th) - pick(ref))),
+                                                     "gpu_vs_torch": _delta_stats(np.abs(pick(gh) - pick(th))),
+                                                     "frames": nf, "what": "xywh of the anchors kept by NMS, pre-scale-back; float64 = the same fused program in double"}
+    except Exception as e:          # the yardstick is a report, not a gate of the benchmark
+        out["kept_anchor_box_abs_err_px"] = {"error": repr(e)}
+    return out
+
+
+def half_parity_report(model_name: str, sd, frames_np, size: int, half_model) -> dict:
+    """half=True has no CPU reference run (Ultralytics refuses half on CPU): its post-NMS rows are measured against the fp32
+    ENGINE's rows on the same frames, matched by source anchor."""
+    import torch
+    from cvsd_amd import YOLO
+    from cvsd_amd.weights import build_from_state_dict
+    m32 = YOLO(build_from_state_dict(model_name, sd), device=torch.cuda.current_device(), batch_chunk=len(frames_np))
+    r32 = m32.predict(frames_np, imgsz=size)
+    r16 = half_model.predict(frames_np, imgsz=size)
+    matched = total = flips = 0
+    d_box, d_score = [], []
+    for a, b in zip(r32, r16):
+        ia = {int(k): i for i, k in enumerate(a.anchor_idx)}
+        ib = {int(k): i for i, k in enumerate(b.anchor_idx)}
+        common = sorted(set(ia) & set(ib))
+        total += len(set(ia) | set(ib))
+        matched += len(common)
+        for k in common:
+            da, db = a.boxes.data.numpy()[ia[k]], b.boxes.data.numpy()[ib[k]]
+            d_box.append(float(np.abs(da[:4] - db[:4]).max()))
+            d_score.append(abs(float(da[4] - db[4])))
+            flips += int(da[5] != db[5])
+    del m32
+    torch.cuda.empty_cache()
+    return {"vs": "the fp32 engine on the same frames (no CPU reference exists for half=True), rows matched by source anchor",
+            "frames": len(frames_np), "rows_matched": matched, "rows_total": total, "class_flips": flips,
+            "row_box_abs_err_px": {"median": float(f"{np.median(d_box):.3e}") if d_box else None, "max": float(f"{max(d_box):.3e}") if d_box else None},
+            "row_score_abs_err_max": float(f"{max(d_score):.3e}") if d_score else None}
+
+
+def cpu_reference(model_name: str, sd, frames_np, size: int, batch: int, budget_s: float, fp32_note: str = "") -> tuple:
+    """the torch-CPU oracle (restated Ultralytics CPU path, fp32, all host cores) on `batch` frames of
+    this config: 3 warm-ups, then the MEDIAN of up to 20 timed iterations within a wall-clock budget; end-to-end (letterbox +
+    /255 -> net -> NMS -> scale-back rows) and net-only (the forward pass alone) reported separately.
+    -> (report dict, the oracle's rows of the last iteration for the parity figures)."""
+    import platform
+    import torch
+    from oracle import yolo_oracle as O
+    om = O.OracleModel(model_name, sd)
+    reps = (batch + len(frames_np) - 1) // len(frames_np)
+    sample = list(np.concatenate([frames_np] * reps)[:batch]) if reps > 1 else list(frames_np[:batch])
+
+    def one():
+        t0 = time.perf_counter()
+        im = O.preprocess(sample, size)
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            pred = om.forward(im)
+        t2 = time.perf_counter()
+        rows, idxs = O.non_max_suppression(pred, 0.25, 0.7, max_det=300, nc=om.nc, return_idxs=True)
+        res = []
+        for r, ai, f in zip(rows, idxs, sample):
+            r = r.clone()
+            r[:, :4] = O.scale_boxes(im.shape[2:], r[:, :4], f.shape)
+            k = O.scale_coords(im.shape[2:], r[:, 6:].view(len(r), *om.kpt_shape).clone(), f.shape) if om.pose else None
+            res.append({"boxes": r[:, :6], "kpts": k, "anchor_idx": ai})
+        t3 = time.perf_counter()
+        return (t3 - t0, t2 - t1, t1 - t0, t3 - t2), res
+
+    t_start = time.perf_counter()
+    (first, want) = one()
+    warm = 3 if first[0] * 6 < budget_s else 1          # a slow config keeps its budget for timed iterations
+    for _ in range(warm - 1):
+        one()
+    times = []
+    t_loop = time.perf_counter()
+    while len(times) < 20 and (len(times) < 3 or time.perf_counter() - t_loop + (times[-1][0] if times else 0) < budget_s):
+        t, want = one()
+        times.append(t)
+    tt = np.array(times)
+    med = np.median(tt, axis=0)
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
+    rep = {"value": round(batch / med[0], 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+           "end_to_end": {"frames_per_s": round(batch / med[0], 2), "median_ms": round(med[0] * 1e3, 2),
+                          "min_ms": round(float(tt[:, 0].min()) * 1e3, 2), "max_ms": round(float(tt[:, 0].max()) * 1e3, 2)},
+           "net_only": {"frames_per_s": round(batch / med[1], 2), "median_ms": round(med[1] * 1e3, 2)},
+           "preprocess_median_ms": round(med[2] * 1e3, 2), "postprocess_median_ms": round(med[3] * 1e3, 2),
+           "batch": batch, "warmups": warm, "iterations": len(times), "budget_s": budget_s,
+           "nproc": os.cpu_count(), "cpu_model": cpu_model or platform.processor(), "torch": torch.__version__,
+           "sample": f"{batch} frames per iteration ({len(frames_np)} distinct synthetic frames" + (", repeated" if reps > 1 else "") +
+                     f") through oracle/yolo_oracle.py: torch {torch.__version__} CPU fp32, {torch.get_num_threads()} threads; "
+                     f"{warm} warm-ups, median of {len(times)} iterations, {time.perf_counter() - t_start:.1f} s of CPU work" + fp32_note}
+    return rep, want
+
+
+def measure_config(model_name: str, size: int, batch: int, half: bool, steps: int, warmup: int, cpu_budget_s: float = 0.0,
+                   with_cpu: bool = True) -> dict:
+    """One BASELINE configuration on this GPU: frames resident in HBM, rows returned to the host every step; beside it the
+    torch-CPU reference at the same batch and the parity figures of the same frames."""
     import torch
     from cvsd_amd import YOLO
     from cvsd_amd.weights import build_from_state_dict
     from tools import synth
     _, sd = synth.synthetic_checkpoint(model_name, seed=0)
     model = YOLO(build_from_state_dict(model_name, sd), device=torch.cuda.current_device(), batch_chunk=batch, half=half)
-    frames, _ = make_frames(batch, size, seed=2000 + batch)
+    frames, frames_np = make_frames(batch, size, seed=2000 + batch)
     for _ in range(warmup):
         model._infer_rows(frames, 0.25, 0.7, None, 300, size)
     torch.cuda.synchronize()
@@ -108,12 +265,76 @@ def measure_config(model_name: str, size: int, batch: int, half: bool, steps: in
     conv_ms, launches, _ = profile_convs(model, frames, size, steps=2)
     achieved = conv_flops_per_frame(model_name, size) * batch / (conv_ms * 1e-3) / 1e12
     peak = F16_PEAK_TFLOPS if half else FP32_PEAK_TFLOPS
-    del model, frames
+    plan = model.plan_info()
+    out = {"workload": f"{model_name} {size}x{size} batch {batch}" + (" half=True" if half else ""), "dtype": "f16" if half else "f32",
+           "value": round(batch * steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "roofline": {"achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                        "launches_per_step": launches, "plan_hash": plan["plan_hash"], "plan_source": plan["plan_source"]},
+           "activation_bytes": plan["activation_bytes"]}
+    del frames
+    if with_cpu and cpu_budget_s > 0:
+        n_par = min(batch, len(frames_np))
+        if half:
+            out["cpu_baseline"], _ = cpu_reference(model_name, sd, frames_np, size, batch, cpu_budget_s,
+                                                   fp32_note="; fp32 on the CPU (Ultralytics refuses half=True on CPU: there is no fp16 CPU path to time)")
+            out["parity"] = half_parity_report(model_name, sd, frames_np[:n_par], size, model)
+        else:
+            out["cpu_baseline"], want = cpu_reference(model_name, sd, frames_np, size, batch, cpu_budget_s)
+            out["parity"] = parity_report(model, model_name, sd, frames_np[:n_par], size, want=want[:n_par],
+                                          f64_frames=1 if conv_flops_per_frame(model_name, size) > 2e10 else 2)
+    del model
     torch.cuda.empty_cache()
-    return {"workload": f"{model_name} {size}x{size} batch {batch}" + (" half=True" if half else ""), "dtype": "f16" if half else "f32",
-            "value": round(batch * steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-            "roofline": {"achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "launches_per_step": launches}}
+    return out
+
+
+def launch_ranks(n: int, argv: list) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N FRESH child processes of this script, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relay rank 0's single JSON line and return the first non-zero child exit
+    code (0 when all ranks succeeded).  Runs before anything in this process has touched the GPU (torch is not even
+    imported here): a process that has initialised HIP must never be re-executed on this pool, and it is not -- the parent
+    only waits.  A rank that fails takes the others down with it (exact PIDs), so a broken rank cannot hang the job in a
+    collective."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this host driver (RCCL needs it)
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0's stdout carries the JSON line; the other ranks' stdout goes to stderr so that exactly one line is relayed
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, cwd=os.getcwd(),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    for line in out0:
+        if rc == 0 or not line.startswith("{"):               # a failed job prints no result line
+            sys.stdout.write(line)
+    sys.stdout.flush()
+    if rc == 0 and sum(l.startswith("{") for l in out0) != 1:
+        print("bench.py: rank 0 did not print exactly one JSON line", file=sys.stderr)
+        rc = 1
+    return rc
 
 
 def main() -> None:
@@ -136,6 +357,11 @@ def main() -> None:
     args = ap.parse_args()
     if args.chunk <= 0:
         args.chunk = args.batch
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (no torch, no HIP call before or after)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -152,6 +378,8 @@ def main() -> None:
     dry = os.environ.get("BENCH_DRYRUN_ONE_GPU") == "1"
     if dry:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible (--gpus {args.gpus})")
     torch.cuda.set_device(local_rank)
     backend = None
     if world > 1:
@@ -232,6 +460,10 @@ def main() -> None:
     # ---- roofline of the dominant kernel (implicit-GEMM conv), HIP events on the engine's stream ----
     PROF_STEPS = 3
     conv_ms, launches, kinds = profile_convs(model, frames, args.size, PROF_STEPS)
+    # the world size the collective library itself reports (RCCL's communicator when backend == "nccl")
+    comm_world = dist.get_world_size() if world > 1 else 1
+    if world > 1:
+        backend = dist.get_backend()
 
     if rank != 0:
         if world > 1:
@@ -242,14 +474,20 @@ def main() -> None:
     scale = (args.size / 640.0) ** 2
     achieved = conv_flops_frame * B / (conv_ms * 1e-3) / 1e12
     fps = world * B * args.steps / dt
-    # HBM traffic of the conv launches from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
-    # process); only quoted when it was collected on this exact workload
-    traffic = None
-    for tname in ("r02_conv_traffic.json", "r01_conv_traffic.json"):
+    # HBM traffic per conv launch cannot be measured inside this process (rocprofv3 PMC passes are separate runs: the guide's
+    # HBM section); the figure collected on this exact workload is kept under profiles/ and quoted ONLY with its source
+    # named and only while the launch sequence it was collected on has the same length as this run's -- else null.
+    traffic, traffic_source = None, None
+    for tname in ("r03_conv_traffic.json", "r02_conv_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and args.model == "yolov8n" and args.size == 640 and B == 512 and args.chunk == 512 and not args.half:
             with open(tpath) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch_avg"]
+                tj = json.load(f)
+            if int(tj.get("launches_per_step", -1)) == launches:
+                traffic = tj["hbm_bytes_per_launch_avg"]
+                traffic_source = f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate run of this command; not measured in this process)"
+            else:
+                traffic_source = f"profiles/{tname} not quoted: collected on {tj.get('launches_per_step')} launches per step, this run has {launches}"
             break
     peak = F16_PEAK_TFLOPS if args.half else FP32_PEAK_TFLOPS
     line = {
@@ -259,15 +497,20 @@ def main() -> None:
         "config": {"workload": f"{args.model} {args.size}x{args.size} synthetic BGR frames ({B} distinct frames per GPU), batch {B}/GPU/step, "
                                f"predict conf=0.25 iou=0.7 max_det=300 (letterbox+stem, conv graph, decode, NMS, rows to host)",
                    "global_batch": B * world, "params": params, "gflop_per_frame": round(gflops * scale, 3),
-                   "parallelism": f"frame-sharded dp{world}", "collectives_backend": backend, "ranks": world},
+                   "parallelism": f"frame-sharded dp{world}", "collectives_backend": backend, "ranks": world,
+                   "collective_world_size": comm_world,
+                   "collectives_per_step": 0 if world == 1 else 2},
         "roofline": {"bound": "mfma", "kernel": ("conv_igemm_f16 + conv1x1_pipe_f16" if args.half else "conv_igemm_f32 + conv1x1_pipe_f32 + conv1x1_stream_f32") + " (every conv launch of a step)",
                      "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                     "traffic": traffic, "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
+                     "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
                      "launches_per_step": launches,
                      "flop_per_launch_avg": conv_flops_frame * B / max(launches, 1)},
         "device_ms_per_step": {k: round(v, 3) for k, v in kinds.items()},
     }
     headline_default = (args.model == "yolov8n" and args.size == 640 and B == 512 and not args.half and not args.host_frames)
+    plan = model.plan_info()
+    line["roofline"]["plan_hash"], line["roofline"]["plan_source"] = plan["plan_hash"], plan["plan_source"]
+    line["config"]["activation_bytes_per_gpu"] = plan["activation_bytes"]
     if world == 1 and not args.no_cpu_baseline and not args.half:
         line["cpu_baseline"] = cpu_baseline(args, sd, frames_np, model)
     if world == 1 and headline_default and not args.no_configs:
@@ -288,59 +531,29 @@ def main() -> None:
                                   "what": "same workload, frames in pinned host memory, engine chunk 128 (H2D of chunk k+1 overlaps chunk k)"}
         del m2, host, frames
         torch.cuda.empty_cache()
-        line["configs"] = [measure_config(*c) for c in EXTRA_CONFIGS]
+        line["configs"] = [measure_config(*c, with_cpu=not args.no_cpu_baseline) for c in EXTRA_CONFIGS]
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
 def cpu_baseline(args, sd, frames_np, model):
-    """The torch-CPU oracle (a restatement of the Ultralytics CPU path: kind 'port') timed on the host cores on a
-    bounded sample of the same workload; the same frames go through the GPU path for a parity figure, and both are
-    measured against a float64 execution of the same program (tools/precision.py)."""
-    import torch
-    from oracle import yolo_oracle as O
-    om = O.OracleModel(args.model, sd)
+    """The headline's CPU baseline: the torch-CPU oracle (kind 'port': a restatement of the Ultralytics CPU path, which is
+    not installable here) on a bounded sample of the benchmark's frames, timed as BASELINE.md section 4 prescribes; the same
+    frames go through the GPU path for the parity figures (indices, post-NMS deltas, fraction within 1e-3, both fp32
+    implementations against float64) and two of them through the canonical-order C oracle (bit-exact gate)."""
     n = min(args.cpu_frames, len(frames_np))
-    sample = list(frames_np[:n])
-    O.predict(om, sample[:2], imgsz=args.size)                     # warm-up
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        want, _ = O.predict(om, sample, imgsz=args.size)
-        reps += 1
-        if time.perf_counter() - t0 > 10.0 or reps >= 5:
-            break
-    dt = time.perf_counter() - t0
-    got = model.predict(frames_np[:n], imgsz=args.size)
-    same = sum(int(np.array_equal(g.anchor_idx, w["anchor_idx"].numpy())) for g, w in zip(got, want))
-    err = 0.0
-    for g, w in zip(got, want):
-        if np.array_equal(g.anchor_idx, w["anchor_idx"].numpy()) and len(g.anchor_idx):
-            err = max(err, float(np.abs(g.boxes.data.numpy()[:, :4] - w["boxes"].numpy()[:, :4]).max()))
+    rep, want = cpu_reference(args.model, sd, frames_np[:n], args.size, n, HEADLINE_CPU_BUDGET_S)
+    parity = parity_report(model, args.model, sd, frames_np[:n], args.size, want=want)
     # the canonical-operation-order C oracle on 2 of the frames: the GPU rows must be identical bit for bit
     from oracle import det
-    dwant, _ = det.predict(det.DetOracleModel(args.model, sd), sample[:2], imgsz=args.size)
-    bit_exact = all(np.array_equal(g.anchor_idx, w["anchor_idx"].numpy()) and
-                    np.array_equal(g.boxes.data.numpy(), w["boxes"].numpy()) for g, w in zip(got[:2], dwant))
-    parity = {"frames_with_identical_indices": same, "frames": n, "max_box_abs_err_px": err,
-              "rows_bit_exact_vs_canonical_order_oracle": bool(bit_exact)}
-    # both fp32 implementations against float64 on 2 of the frames (pre-NMS head tensor, box channels, pixels)
-    try:
-        from tools import precision as P
-        nf = min(2, n)
-        ref = P.f64_head(args.model, sd, frames_np[:nf], args.size)
-        e_gpu = P.group_errors(model.raw_head(frames_np[:nf], imgsz=args.size), ref, model.nc)["box"]
-        e_cpu = P.group_errors(om.forward(O.preprocess(sample[:nf], args.size)).numpy(), ref, model.nc)["box"]
-        parity["err_vs_f64_px"] = {"gpu": {k: float(f"{v:.3e}") for k, v in e_gpu.items()},
-                                   "torch_cpu": {k: float(f"{v:.3e}") for k, v in e_cpu.items()}, "frames": nf,
-                                   "what": "pre-NMS box channels vs a float64 execution of the same fused program"}
-    except Exception as e:      # the yardstick is a report, not a gate of the benchmark
-        parity["err_vs_f64_px"] = {"error": repr(e)}
-    return {"value": round(n * reps / dt, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} of the benchmark frames x {reps} passes through oracle/yolo_oracle.py (torch {torch.__version__} "
-                      f"CPU fp32, batch {n})",
-            "parity_vs_gpu": parity}
+    got = model.predict(frames_np[:2], imgsz=args.size)
+    dwant, _ = det.predict(det.DetOracleModel(args.model, sd), list(frames_np[:2]), imgsz=args.size)
+    parity["rows_bit_exact_vs_canonical_order_oracle"] = bool(all(
+        np.array_equal(g.anchor_idx, w["anchor_idx"].numpy()) and np.array_equal(g.boxes.data.numpy(), w["boxes"].numpy())
+        for g, w in zip(got, dwant)))
+    rep["parity_vs_gpu"] = parity
+    return rep
 
 
 if __name__ == "__main__":

@@ -61,6 +61,7 @@ SIGNATURES = {
     "mi355_yolo_sync": (C.c_int, [C.c_void_p]),
     "mi355_yolo_raw_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       _i32p, _i32p]),
+    "mi355_yolo_plan_info": (C.c_int, [C.c_void_p, _P(C.c_ulonglong), _i32p, _i32p, _P(C.c_longlong)]),
     "mi355_yolo_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mi355_yolo_last_timing": (C.c_int, [C.c_void_p, _P(Timing)]),
     "mi355_op_conv2d": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -73,6 +74,7 @@ SIGNATURES = {
                                             C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, _i32p]),
     "mi355_bench_conv2d": (C.c_int, [C.c_int] * 12 + [_f32p, _i32p, C.c_char_p, C.c_int]),
     "mi355_bench_conv2d_f16": (C.c_int, [C.c_int] * 12 + [_f32p, _i32p, C.c_char_p, C.c_int]),
+    "mi355_plan_query": (C.c_int, [C.c_int] * 13 + [_i32p, C.c_int, _i32p]),
     "mi355_op_stem": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_int, C.c_int, C.c_void_p]),
     "mi355_letterbox_shape": (C.c_int, [C.c_int, C.c_int, C.c_int, _i32p, _i32p]),

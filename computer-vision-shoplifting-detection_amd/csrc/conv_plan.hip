@@ -306,10 +306,15 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     a.fd_tx = make_fastdiv((unsigned)std::max(1, a.tiles_x)); a.fd_ty = make_fastdiv((unsigned)std::max(1, a.tiles_y));
     a.fd_gy = make_fastdiv(std::max(1u, out->grid_y));
     if (!half && (p.version == 1 || p.f2)) {
-        // conv_igemm_f32 addresses one image of each slice with 32-bit byte offsets (a pointwise launch sees the flattened
-        // batch as one image): such a plan is not offered beyond 2^30 elements (the streaming / pipelined kernels remain)
+        // conv_igemm_f32 addresses one image of each slice through a buffer descriptor with 32-bit byte offsets (a pointwise
+        // launch sees the flattened batch as one image), and lanes / pad channels whose store must be DROPPED are given the
+        // byte offset 0x80000000: that marker is out of range only while num_records <= 2^31 bytes, i.e. while every slice
+        // image -- source, destination, residual and the fused stage's destination -- stays below 2^29 elements.  Beyond that
+        // such a plan is not offered (the streaming / pipelined pointwise kernels use per-block descriptors and remain).
+        const long long lim = 1ll << 29;
         const long long e_src = (long long)a.Hin * a.Win * a.src_cs, e_dst = (long long)a.Hout * a.Wout * std::max(a.dst_cs, a.res_cs);
-        if (e_src >= (1ll << 30) || e_dst >= (1ll << 30)) return "conv: image too large for the 32-bit offsets of conv_igemm_f32";
+        const long long e_dst2 = p.f2 ? (long long)a.Hout * a.Wout * a.dst2_cs : 0;
+        if (e_src >= lim || e_dst >= lim || e_dst2 >= lim) return "conv: image too large for the 32-bit offsets of conv_igemm_f32";
     }
     a.img_src = a.Hin * a.Win * a.src_cs; a.img_dst = a.Hout * a.Wout * a.dst_cs; a.img_res = a.Hout * a.Wout * a.res_cs;
     out->lds = p.lds;

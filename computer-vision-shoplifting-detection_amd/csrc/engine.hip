@@ -128,6 +128,7 @@ struct mi355_yolo {
     // (cur_nb, cur_H, cur_W) and are rebuilt -- from the tuned-choice cache, without touching the buffers -- when only the
     // frame count of a call changes (sweep tails, track() at n = 1 between batched predicts)
     int cur_nb = 0, cur_H = 0, cur_W = 0, alloc_nb = 0;
+    long long act_bytes = 0;            // bytes of activation buffers currently allocated
     unsigned long long model_hash = 0;  // FNV-1a of the .mi355w image: key of the persisted plan choices
     std::vector<float*> dbuf;           // activation buffers (fp32, or fp16 bytes behind a float* when `half`)
     std::vector<int> dbuf_cs;           // pixel stride in ELEMENTS of the buffer's dtype
@@ -173,6 +174,8 @@ struct mi355_yolo {
     unsigned* d_cmask = nullptr; unsigned* h_cmask = nullptr; int cmask_words = 0;
     int* d_xtab = nullptr; int* d_ytab = nullptr; int tab_h0 = -1, tab_w0 = -1, tab_imgsz = -1;
     float* d_rawhead = nullptr; size_t rawhead_floats = 0;
+    unsigned long long plan_hash = 0;   // fingerprint of the candidate lists + the chosen indices of the current shape
+    int plan_source = 0, plan_launches = 0;   // 0 static guess (autotune off), 1 memory, 2 plan file, 3 tuned now; launches of one pass (stem..last conv)
     bool async_pending = false;         // mi355_yolo_infer_device_async work may still be in flight on `stream`
     // timing
     bool profiling = false;
@@ -194,6 +197,7 @@ void mi355_yolo::free_shape() {
     if (lbox) (void)hipFree(lbox);
     pred = nullptr; best = nullptr; keys = nullptr; lbox = nullptr;
     cur_nb = cur_H = cur_W = alloc_nb = 0;
+    act_bytes = 0;
 }
 
 mi355_yolo::~mi355_yolo() {
@@ -438,7 +442,24 @@ static int build_schedule(mi355_yolo* h) {
 // process) need not repeat it.  The autotuner's CHOICES -- an index into each conv's candidate list -- are kept in a small
 // text file keyed by (model image hash, precision, frames, H, W, planner version); a file whose candidate counts do not
 // match the running planner is ignored.  MI355_PLAN_CACHE=<dir> moves the directory, MI355_PLAN_CACHE=0 turns it off.
-static const char* kPlanVersion = "mi355-plans-r02h";
+static const char* kPlanVersion = "mi355-plans-r03a";
+
+// What a persisted choice (an INDEX into a candidate list) means depends on the lists themselves: the planner build, its env
+// knobs, the GPU.  The file therefore carries a fingerprint of every candidate's launch geometry plus the device's arch name
+// and CU count; a file written by another build / device / knob setting does not match and is ignored (then overwritten).
+static unsigned long long fnv1a(unsigned long long h, const void* p, size_t n) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+static unsigned long long cand_fingerprint(unsigned long long hsh, const std::vector<ConvLaunch>& list) {
+    for (const ConvLaunch& l : list) {
+        const int f[] = {l.version, l.CT, l.PT, l.WP, l.a.TW, l.a.TH, l.a.ck, l.a.cgroups, (int)l.lds, (int)l.grid_x, (int)l.grid_y, l.a.w2 ? 1 : 0, l.a.up_c};
+        hsh = fnv1a(hsh, f, sizeof(f));
+    }
+    const int end = -1;
+    return fnv1a(hsh, &end, sizeof(end));
+}
 
 static std::string plan_cache_path(const mi355_yolo* h, int nb, int Hl, int Wl) {
     const char* e = getenv("MI355_PLAN_CACHE");
@@ -456,14 +477,16 @@ static std::string plan_cache_path(const mi355_yolo* h, int nb, int Hl, int Wl) 
 
 constexpr int kUpBase = 10000;       // chosen[i] >= kUpBase: the conv reads the upsample kernel's output with plan chosen[i] - kUpBase
 
-static bool load_plan_choices(const mi355_yolo* h, int nb, int Hl, int Wl, const std::vector<int>& n_cands, std::vector<int>* chosen) {
+static bool load_plan_choices(const mi355_yolo* h, int nb, int Hl, int Wl, const std::vector<int>& n_cands, unsigned long long fp,
+                              std::vector<int>* chosen) {
     const std::string path = plan_cache_path(h, nb, Hl, Wl);
     if (path.empty()) return false;
     FILE* f = std::fopen(path.c_str(), "r");
     if (!f) return false;
     char ver[64] = {0};
     int n = 0;
-    bool ok = std::fscanf(f, "%63s %d", ver, &n) == 2 && std::strcmp(ver, kPlanVersion) == 0 && n == (int)n_cands.size();
+    unsigned long long got_fp = 0;
+    bool ok = std::fscanf(f, "%63s %d %llx", ver, &n, &got_fp) == 3 && std::strcmp(ver, kPlanVersion) == 0 && n == (int)n_cands.size() && got_fp == fp;
     std::vector<int> got(n_cands.size(), 0);
     for (size_t i = 0; ok && i < n_cands.size(); ++i) {
         int c = 0, nc = 0;
@@ -478,13 +501,14 @@ static bool load_plan_choices(const mi355_yolo* h, int nb, int Hl, int Wl, const
     return ok;
 }
 
-static void save_plan_choices(const mi355_yolo* h, int nb, int Hl, int Wl, const std::vector<int>& n_cands, const std::vector<int>& chosen) {
+static void save_plan_choices(const mi355_yolo* h, int nb, int Hl, int Wl, const std::vector<int>& n_cands, unsigned long long fp,
+                              const std::vector<int>& chosen) {
     const std::string path = plan_cache_path(h, nb, Hl, Wl);
     if (path.empty()) return;
     const std::string tmp = path + "." + std::to_string((long)getpid());
     FILE* f = std::fopen(tmp.c_str(), "w");
     if (!f) return;
-    std::fprintf(f, "%s %zu\n", kPlanVersion, n_cands.size());
+    std::fprintf(f, "%s %zu %llx\n", kPlanVersion, n_cands.size(), fp);
     for (size_t i = 0; i < n_cands.size(); ++i) std::fprintf(f, "%d/%d\n", chosen[i], n_cands[i]);
     std::fclose(f);
     if (std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());   // atomic: ranks may race
@@ -508,6 +532,7 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
             h->dbuf_es[i] = es;
             const size_t bytes = (size_t)nb * (Hl / h->bufs[i].stride_div) * (Wl / h->bufs[i].stride_div) * cs * es;
             HIPCHK(hipMalloc(&h->dbuf[i], bytes));
+            h->act_bytes += (long long)bytes;
             HIPCHK(hipMemsetAsync(h->dbuf[i], 0, bytes, h->stream));   // pad channels stay zero forever
             h->dbuf_cs[i] = cs;
         }
@@ -521,6 +546,7 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
         h->alloc_nb = nb; h->cur_H = Hl; h->cur_W = Wl;
     }
     // ---- launch plans for nb frames per pass on the existing buffers ----
+    h->cur_nb = 0;                      // a rebuild that fails half-way is retried by the next call instead of running stale plans
     for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.second);      // captured launches embed the old plans
     h->graphs.clear();
     h->plans.assign(h->ops.size(), ConvLaunch{});
@@ -589,7 +615,17 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
     std::vector<int> chosen(h->ops.size(), 0);
     bool have = false;
     for (const auto& t : h->tuned) if (t.first == shape_key) { chosen = t.second; have = true; }
-    if (!have && h->autotune) have = load_plan_choices(h, nb, Hl, Wl, n_cands, &chosen);
+    unsigned long long fp = 1469598103934665603ull;
+    {
+        hipDeviceProp_t prop{};
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) {
+            fp = fnv1a(fp, prop.gcnArchName, std::strlen(prop.gcnArchName));
+            fp = fnv1a(fp, &prop.multiProcessorCount, sizeof(int));
+        }
+        for (size_t i = 0; i < h->ops.size(); ++i) { fp = cand_fingerprint(fp, cands[i]); fp = cand_fingerprint(fp, cands_f[i]); fp = cand_fingerprint(fp, cands_u[i]); }
+    }
+    h->plan_source = have ? 1 : 0;          // 1 = this process's memory
+    if (!have && h->autotune) { have = load_plan_choices(h, nb, Hl, Wl, n_cands, fp, &chosen); if (have) h->plan_source = 2; }
     auto run_upsample = [&](int ui) -> int {
         const FileOp& u = h->ops[ui];
         const int sd_in = h->bufs[u.src_buf].stride_div, dv = h->dbuf_es[u.src_buf] == 2 ? 2 : 1;
@@ -673,8 +709,9 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
             }
         }
         h->tuned.push_back({shape_key, chosen});
-        save_plan_choices(h, nb, Hl, Wl, n_cands, chosen);
+        save_plan_choices(h, nb, Hl, Wl, n_cands, fp, chosen);
         have = true;
+        h->plan_source = 3;
     }
     if (have) {
         for (size_t i = 0; i < h->ops.size(); ++i) {
@@ -694,6 +731,10 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
         if (!known) h->tuned.push_back({shape_key, chosen});
     }
     h->cur_nb = nb;
+    h->plan_hash = fnv1a(fp, chosen.data(), chosen.size() * sizeof(int));     // candidates + choices: identifies the launch sequence
+    h->plan_launches = 0;
+    for (size_t i = 0; i < h->ops.size(); ++i)
+        h->plan_launches += !(h->ops[i].type == OP_UPSAMPLE && h->fused_away[i]) && !h->skip_op[i];
     if (getenv("MI355_SCHED_LOG")) {      // launch order of a pass for tools/layer_report.py: position, op index, stream, launched
         for (size_t pos = 0; pos < h->sched_order.size(); ++pos) {
             const int idx = h->sched_order[pos];
@@ -1169,6 +1210,15 @@ int mi355_yolo_sync(mi355_yolo* h) {
     return MI355_OK;
 }
 
+int mi355_yolo_plan_info(const mi355_yolo* h, unsigned long long* plan_hash, int* source, int* launches, long long* activation_bytes) {
+    if (!h) return fail(MI355_EINVAL, "null argument");
+    if (plan_hash) *plan_hash = h->plan_hash;
+    if (source) *source = h->plan_source;
+    if (launches) *launches = h->plan_launches;
+    if (activation_bytes) *activation_bytes = h->act_bytes;
+    return MI355_OK;
+}
+
 int mi355_yolo_set_profiling(mi355_yolo* h, int on) {
     if (!h) return fail(MI355_EINVAL, "null argument");
     h->profiling = on != 0;
@@ -1486,6 +1536,26 @@ int mi355_bench_conv2d_f16(int device_id, int n, int h, int w, int cin, int cout
                            int plan_index, int iters, float* avg_ms, int* n_plans, char* plan_desc, int plan_desc_len) {
     return bench_conv2d_impl(device_id, n, h, w, cin, cout, k, stride, silu, residual, plan_index, iters, avg_ms, n_plans, plan_desc,
                              plan_desc_len, true);
+}
+
+// Host-only view of the launch planner (no kernel is launched, no device memory is touched): which kernel versions would be
+// offered for a conv of this shape and these buffer strides.  Used by the CPU tests of the planner's guards.
+int mi355_plan_query(int n, int h, int w, int cin, int cout, int k, int stride, int src_cs, int dst_cs, int res_cs, int f2_cout,
+                     int f2_dst_cs, int half, int* versions, int cap, int* n_plans) {
+    if (!n_plans || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || cap < 0 || (cap > 0 && !versions)) return fail(MI355_EINVAL, "bad argument");
+    if (stride != 1 && stride != 2) return fail(MI355_EINVAL, "stride must be 1 or 2");
+    float* fake = (float*)(uintptr_t)0x10000;                    // aligned, never dereferenced
+    ConvArgs a{};
+    a.src = fake; a.src_cs = src_cs; a.dst = fake; a.dst_cs = dst_cs; a.res = res_cs ? fake : nullptr; a.res_cs = res_cs;
+    a.wpk = fake; a.bias = fake; a.zeros = fake;
+    a.B = n; a.Hin = h; a.Win = w; a.Hout = h / stride; a.Wout = w / stride; a.Cin = cin; a.Cout = cout; a.k = k; a.stride = stride;
+    a.pad = k / 2; a.act = 1; a.dtype = half ? 1 : 0;
+    if (f2_cout > 0) { a.f2_wpk = fake; a.f2_bias = fake; a.f2_dst = fake; a.f2_dst_cs = f2_dst_cs; a.f2_cout = f2_cout; a.f2_act = 0; }
+    std::vector<ConvLaunch> cands;
+    if (const char* e = plan_conv_candidates(a, &cands)) { *n_plans = 0; return fail(MI355_EINVAL, e); }
+    *n_plans = (int)cands.size();
+    for (int i = 0; i < (int)cands.size() && i < cap; ++i) versions[i] = cands[i].version + (cands[i].a.w2 ? 100 : 0);
+    return MI355_OK;
 }
 
 int mi355_op_stem(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias, int cout,

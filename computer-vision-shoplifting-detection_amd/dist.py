@@ -71,7 +71,7 @@ def gather_rows(rows: np.ndarray, counts: np.ndarray, dst: int = 0, ncols: Optio
     c = torch.as_tensor(np.asarray(counts, dtype=np.int32), device=dev)
     all_c = [torch.empty_like(c) for _ in range(world)]
     dist.all_gather(all_c, c)                                        # C2
-    totals = [int(x.sum().item()) for x in all_c]
+    totals = [int(t) for t in torch.stack(all_c).sum(dim=1).cpu().tolist()]
     width = rows.shape[-1]
     m = max(max(totals), 1)
     pad = torch.zeros((m, width), dtype=torch.float32, device=dev)
@@ -116,7 +116,7 @@ class DeviceRowGather:
         c = counts if nccl else counts.cpu()
         all_c = [torch.empty_like(c) for _ in range(world)]
         dist.all_gather(all_c, c)                                        # C2
-        totals = [int(x.sum().item()) for x in all_c]
+        totals = [int(t) for t in torch.stack(all_c).sum(dim=1).cpu().tolist()]   # ONE device->host sync per step, not one per rank
         m = max(max(totals), 1)
         block = rows[:m] if self.ncols is None else rows[:m, :self.ncols]
         block = block.contiguous() if nccl else block.cpu().contiguous()

@@ -192,6 +192,7 @@ class YOLO:
             cl = [int(classes)] if np.isscalar(classes) else [int(c) for c in classes]
             cls_arr, ncls = (C.c_int * len(cl))(*cl), len(cl)
         hnd = self._handle(half)
+        self._async_handle = hnd              # `stream` / `sync()` refer to the engine that received the last asynchronous call
         with self._lock:
             torch.cuda.current_stream(frames.device).synchronize()       # the frames must be complete; the engine has its own stream
             _lib.check(_lib.lib().mi355_yolo_infer_device_async(hnd, frames.data_ptr(), n, h, w, float(conf), float(iou), cls_arr, ncls,
@@ -200,13 +201,20 @@ class YOLO:
 
     @property
     def stream(self) -> "torch.cuda.ExternalStream":
-        """The engine's HIP stream as a torch stream (``torch.cuda.current_stream().wait_stream(model.stream)``)."""
-        if getattr(self, "_ext_stream", None) is None:
-            self._ext_stream = torch.cuda.ExternalStream(int(_lib.lib().mi355_yolo_stream(self._h)), device=torch.device("cuda", self.device))
-        return self._ext_stream
+        """The HIP stream of the engine that received the last :meth:`infer_async` call (the primary engine before any), as
+        a torch stream: ``torch.cuda.current_stream().wait_stream(model.stream)``.  A ``half=`` override runs on the second
+        engine, which has a stream of its own -- this property follows it."""
+        hnd = getattr(self, "_async_handle", None) or self._h
+        cache = self.__dict__.setdefault("_ext_streams", {})
+        if hnd.value not in cache:
+            cache[hnd.value] = torch.cuda.ExternalStream(int(_lib.lib().mi355_yolo_stream(hnd)), device=torch.device("cuda", self.device))
+        return cache[hnd.value]
 
     def sync(self) -> None:
-        _lib.check(_lib.lib().mi355_yolo_sync(self._h))
+        """Wait for every asynchronous call enqueued so far (both engines, when a ``half=`` override created the second)."""
+        for hnd in (self._h, self._h_other):
+            if hnd.value:
+                _lib.check(_lib.lib().mi355_yolo_sync(hnd))
 
     def predict(self, source=None, conf: Optional[float] = None, iou: float = 0.7, classes=None, max_det: int = 300,
                 imgsz: int = 640, half: Optional[bool] = None, verbose: bool = False, stream: bool = False, **kwargs
@@ -284,6 +292,14 @@ class YOLO:
             _lib.check(lib.mi355_yolo_raw_head(hnd, batch.ctypes.data, n, h, w, 0, imgsz, out.ctypes.data,
                                                C.byref(ch), C.byref(an)))
         return out
+
+    def plan_info(self) -> dict:
+        """Launch plans of the shape last run: hash (candidates + choices), where the choices came from, launches per pass and
+        the activation footprint in bytes."""
+        hsh, src, nl, ab = C.c_ulonglong(), C.c_int(), C.c_int(), C.c_longlong()
+        _lib.check(_lib.lib().mi355_yolo_plan_info(getattr(self, "_last_handle", self._h), C.byref(hsh), C.byref(src), C.byref(nl), C.byref(ab)))
+        return {"plan_hash": f"{hsh.value:016x}", "plan_source": ("static", "memory", "file", "tuned")[src.value & 3],
+                "launches_per_pass": nl.value, "activation_bytes": ab.value}
 
     def set_profiling(self, on: bool = True) -> None:
         _lib.check(_lib.lib().mi355_yolo_set_profiling(self._h, int(on)))

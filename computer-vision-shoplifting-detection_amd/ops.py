@@ -117,3 +117,16 @@ def nms(pred: np.ndarray, nc: int, conf: float = 0.25, iou: float = 0.7, classes
         ints = r[:, 5:7].view(np.int32)
         out.append((np.concatenate([r[:, :5], ints[:, :1].astype(np.float32), r[:, 7:7 + extra]], 1), ints[:, 1].copy()))
     return out
+
+
+def plan_versions(n: int, h: int, w: int, cin: int, cout: int, k: int, stride: int = 1, src_cs: int = 0, dst_cs: int = 0, res_cs: int = 0,
+                  f2_cout: int = 0, f2_dst_cs: int = 0, half: bool = False):
+    """Kernel versions of the candidate launch plans the planner offers for this conv (host-only query, runs without a GPU):
+    1 LDS-staged implicit GEMM, 3 streaming pointwise, 4 pipelined pointwise, 6 split-K; + 100 = with the fused pointwise stage."""
+    cap = 4096
+    out = (C.c_int * cap)()
+    npl = C.c_int(0)
+    r4 = lambda c: (c + 3) // 4 * 4
+    _lib.check(_lib.lib().mi355_plan_query(n, h, w, cin, cout, k, stride, src_cs or r4(cin), dst_cs or r4(cout), res_cs, f2_cout,
+                                           f2_dst_cs or r4(f2_cout), int(half), out, cap, C.byref(npl)))
+    return [out[i] for i in range(min(cap, npl.value))]

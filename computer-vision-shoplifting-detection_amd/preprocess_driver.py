@@ -64,10 +64,19 @@ class ImageDirCapture:
         self._pos = 0
         for cand in (source, os.path.splitext(source)[0]):
             if os.path.isdir(cand):
-                names = sorted(n for n in os.listdir(cand) if n.lower().endswith(self.EXTS))
+                names = sorted((n for n in os.listdir(cand) if n.lower().endswith(self.EXTS)), key=self._natural_key)
                 if names:
                     self._files = [os.path.join(cand, n) for n in names]
                     break
+
+    @staticmethod
+    def _natural_key(name: str):
+        """Frame order = the numbers in the file name, numerically (``2.jpg`` before ``10.jpg``, ``img_9`` before ``img_10``);
+        text parts compare as text.  A plain string sort would feed 1, 10, 100, 2, ... to the tracker and label the CSV rows
+        with the wrong frame numbers whenever the dump is not zero-padded."""
+        import re
+        stem = os.path.splitext(name)[0]
+        return [(0, int(t), "") if t.isdigit() else (1, 0, t.lower()) for t in re.findall(r"\d+|\D+", stem)], name
 
     def isOpened(self) -> bool:
         return self._files is not None

@@ -140,6 +140,12 @@ int  mi355_yolo_sync(mi355_yolo* h);
 int  mi355_yolo_raw_head(mi355_yolo* h, const uint8_t* bgr_nhwc, int n, int height, int width, int row_stride_bytes,
                          int imgsz, float* out, int* out_channels, int* out_anchors);
 
+/* Launch plans of the shape last run: plan_hash identifies the candidate lists AND the choice per conv (two runs with the same
+ * hash launch the same kernels with the same grids); source 0 = static guess (autotune off), 1 = this process's memory,
+ * 2 = plan file, 3 = timed now; launches = kernel launches of one pass (stem .. last conv; decode and NMS follow);
+ * activation_bytes = device memory held by the activation buffers.  Any out pointer may be NULL. */
+int  mi355_yolo_plan_info(const mi355_yolo* h, unsigned long long* plan_hash, int* source, int* launches,
+                          long long* activation_bytes);
 /* Per-kernel-kind timing costs two HIP events per launch; off by default (total_ms is always measured). */
 int  mi355_yolo_set_profiling(mi355_yolo* h, int on);
 int  mi355_yolo_last_timing(const mi355_yolo* h, mi355_timing* t);
@@ -180,6 +186,12 @@ int  mi355_bench_conv2d(int device_id, int n, int h, int w, int cin, int cout, i
 int  mi355_bench_conv2d_f16(int device_id, int n, int h, int w, int cin, int cout, int k, int stride, int silu,
                             int residual, int plan_index, int iters, float* avg_ms, int* n_plans, char* plan_desc,
                             int plan_desc_len);
+/* Host-only query of the launch planner (nothing is launched or allocated): the kernel version of every candidate launch
+ * plan for a conv of this shape over buffers with these pixel strides (elements); versions[i] = 1 conv_igemm (LDS-staged),
+ * 3 streaming pointwise, 4 pipelined pointwise, 6 split-K, + 100 when the plan carries the fused pointwise stage
+ * (f2_cout > 0).  res_cs = 0: no residual.  For the planner's unit tests (address-range guards). */
+int  mi355_plan_query(int n, int h, int w, int cin, int cout, int k, int stride, int src_cs, int dst_cs, int res_cs,
+                      int f2_cout, int f2_dst_cs, int half, int* versions, int cap, int* n_plans);
 /* The u8 stem: letterboxed BGR frames -> (x/255, RGB) -> conv k x k stride s (pad k/2, or 2 for k=6) + bias + SiLU. */
 int  mi355_op_stem(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias,
                    int cout, int k, int stride, float* y);

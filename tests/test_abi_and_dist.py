@@ -1,6 +1,7 @@
 import os
 import re
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -121,3 +122,18 @@ def test_header_is_plain_c_and_a_c_client_links(tmp_path):
     r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), so,
                         "-Wl,-rpath," + os.path.dirname(so)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_bench_self_launch_without_gpus_returns_nonzero_and_no_result_line():
+    """`python bench.py --gpus 2` starts its own ranks (no torch.distributed.run needed); on a box without GPUs every rank
+    refuses to run (there is no CPU fallback), and the launcher reports that as a non-zero exit without a JSON line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "BENCH_DRYRUN_ONE_GPU")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the failure path is covered by tests/test_gpu_bench.py")
+    assert p.returncode != 0
+    assert "needs an MI355X" in p.stderr or "GPU" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -52,7 +52,7 @@ def _assert_rows_identical(res, want, pose):
             np.testing.assert_array_equal(r.keypoints.data.numpy(), k.numpy())
 
 
-@pytest.mark.parametrize("name,n,size", [("yolov8n", 3, 640), ("yolov8n-pose", 4, 640), ("yolov8n-pose", 2, 320)])
+@pytest.mark.parametrize("name,n,size", [("yolov8n", 3, 640), ("yolov8n", 1, 640), ("yolov8n-pose", 4, 640), ("yolov8n-pose", 2, 320)])
 def test_bit_exact_vs_canonical_order_oracle(name, n, size):
     from oracle import det
     from tools import synth
@@ -81,15 +81,29 @@ def test_bit_exact_ucf_crime_shape_with_resize():
     _assert_rows_identical(res, want, True)
 
 
-def _compare_predictions(m, om, frames, conf, classes=None, max_det=300, imgsz=640):
+# float64 decision margins below which a post-NMS divergence between two fp32 implementations is fp32 noise (the same levels
+# tests/test_gpu_precision.py uses against the float64 run itself)
+MARGIN_NOISE = {"conf threshold": 5e-4, "score order": 5e-4, "iou threshold": 5e-3}
+
+
+def _compare_predictions(m, om, name, sd, frames, conf, classes=None, max_det=300, imgsz=640):
+    """engine rows vs the torch oracle's rows.  A frame whose kept-anchor list differs is NOT skipped: the first divergence
+    must sit on a float64 decision margin (score - conf, IoU - 0.7, score order) below fp32 noise -- two fp32 summation
+    orders may legitimately decide such a case differently -- or the test fails."""
     from oracle import yolo_oracle as O
+    from tools import precision as P
     res = m.predict(frames, conf=conf, classes=classes, max_det=max_det, imgsz=imgsz)
     want, _ = O.predict(om, list(frames), conf=conf, classes=classes, max_det=max_det, imgsz=imgsz)
-    stats = {"frames": len(frames), "rows": 0, "max_box_err": 0.0, "max_kpt_err": 0.0, "index_mismatch_frames": 0}
-    for r, w in zip(res, want):
+    stats = {"frames": len(frames), "rows": 0, "max_box_err": 0.0, "max_kpt_err": 0.0, "index_mismatch_frames": 0, "explained": []}
+    for i, (r, w) in enumerate(zip(res, want)):
         ga, wa = r.anchor_idx, w["anchor_idx"].numpy()
         if len(ga) != len(wa) or not np.array_equal(ga, wa):
             stats["index_mismatch_frames"] += 1
+            ref64 = P.f64_head(name, sd, frames[i:i + 1], imgsz)[0]
+            pos, margin, kind = P.first_divergence_margin(ref64, wa.tolist(), ga.tolist(), m.nc, conf, 0.7)
+            assert margin < MARGIN_NOISE[kind], (f"{name} frame {i}: kept anchors differ from the torch oracle at rank {pos} although the "
+                                                 f"float64 {kind} margin there is {margin:.2e} (not fp32 noise)")
+            stats["explained"].append((i, pos, kind, float(f"{margin:.2e}")))
             continue
         stats["rows"] += len(ga)
         if len(ga) == 0:
@@ -115,11 +129,11 @@ def test_predict_640_matches_oracle(name, n):
     m = _model(name, ckpt)
     om = O.OracleModel(name, ckpt[1])
     frames = synth.synthetic_frames(n, 640, 640, seed=5)
-    st = _compare_predictions(m, om, frames, conf=0.25)
+    st = _compare_predictions(m, om, name, ckpt[1], frames, conf=0.25)
     print(name, st)
-    # vs the torch oracle only re-association noise is allowed (a flipped NMS decision near IoU 0.7 / conf 0.25 can
-    # change a frame's index list; the canonical-order test above pins indices exactly)
-    assert st["rows"] > 0
+    # vs the torch oracle only re-association noise is allowed: every index divergence was explained above by its float64
+    # margin (the canonical-order test pins indices exactly); at least one frame must have compared row by row
+    assert st["rows"] > 0 and st["index_mismatch_frames"] < n
     assert st["max_box_err"] < RAW_BOX_TOL, st
     assert st["max_kpt_err"] < RAW_BOX_TOL, st
 
@@ -131,7 +145,7 @@ def test_predict_ucf_crime_shape_person_class(v8n):
     m = _model("yolov8n", v8n)
     om = O.OracleModel("yolov8n", v8n[1])
     frames = synth.synthetic_frames(3, 240, 320, seed=2)
-    st = _compare_predictions(m, om, frames, conf=0.1, classes=None)
+    st = _compare_predictions(m, om, "yolov8n", v8n[1], frames, conf=0.1, classes=None)
     print(st)
     assert st["max_box_err"] < RAW_BOX_TOL, st
     res = m.predict(frames, conf=0.1, classes=[0])
@@ -215,6 +229,8 @@ def test_track_call_of_the_reference(v8n):
     ("yolov8s-pose", 2, 320, 320, 320),     # config 4's model
     ("yolov8m", 1, 256, 320, 320),          # config 5's model: widths 48/96/192/384/576, deeper C2f
     ("yolov5nu", 2, 320, 320, 320),         # the reference's literal family (yolov5mu.pt): C3 blocks + 6x6 stem
+    ("yolov5mu", 1, 240, 320, 640),         # the reference's literal model AND call: YOLO("yolov5mu.pt") on a 320x240 UCF-Crime
+                                            # frame, batch 1 (/root/reference/model.py:18,38): resize to 480x640, C3 x2/4/6/2
     ("yolov8n", 1, 1280, 1280, 1280),       # 33600 anchors: > 32768 sort keys, global-memory bitonic path
 ])
 def test_bit_exact_other_models_and_sizes(name, n, h, w, imgsz):
@@ -235,21 +251,23 @@ def test_bit_exact_other_models_and_sizes(name, n, h, w, imgsz):
 def test_shape_switching_reuses_tuning_and_stays_exact(v8n):
     """alternating batch sizes / frame sizes: same rows every time (launch plans are cached per shape, and every
     plan gives the same bits anyway)"""
-    import time
     from tools import synth
     m = _model("yolov8n", v8n)
     a = synth.synthetic_frames(5, 128, 160, seed=1)
     b = synth.synthetic_frames(2, 96, 96, seed=2)
     ra = [r.boxes.data.numpy().copy() for r in m.predict(a, conf=0.1, imgsz=160)]
     rb = [r.boxes.data.numpy().copy() for r in m.predict(b, conf=0.1, imgsz=96)]
-    t0 = time.perf_counter()
+    seen = {}
     for _ in range(3):
         for got, want in zip(m.predict(a, conf=0.1, imgsz=160), ra):
             np.testing.assert_array_equal(got.boxes.data.numpy(), want)
         for got, want in zip(m.predict(b, conf=0.1, imgsz=96), rb):
             np.testing.assert_array_equal(got.boxes.data.numpy(), want)
         np.testing.assert_array_equal(m.predict(a[:1], conf=0.1, imgsz=160)[0].boxes.data.numpy(), ra[0])
-    assert time.perf_counter() - t0 < 5.0          # six shape switches without re-timing candidates
+        # a shape seen before is served from this process's memory (never re-timed): same plan hash, source "memory"
+        info = m.plan_info()
+        assert info["plan_source"] == "memory"
+        assert seen.setdefault("hash", info["plan_hash"]) == info["plan_hash"]
 
 
 def test_full_size_batch_properties(v8n_pose):

@@ -137,3 +137,34 @@ def test_engine_to_poselift_reproduces_the_reference_loader_fixture(v8n_pose):
         x, y = windows(data, seq_len=seq_len, stride=stride, include_confidence=True, frame_labels=labels)
         np.testing.assert_array_equal(x, fix[f"{split}_xyc_x"])
         np.testing.assert_array_equal(y, fix[f"{split}_xyc_y"])
+
+
+def test_plan_file_tune_path_and_load_path(v8n, tmp_path, monkeypatch):
+    """the persisted launch-plan choices: a fresh directory makes the first model TUNE (stopwatch) and write the file, a second
+    model of the same image LOADS it (same plan hash, no rewrite); a file from a different planner fingerprint is ignored"""
+    import glob
+    import torch
+    from cvsd_amd import YOLO
+    from tools import synth
+    monkeypatch.setenv("MI355_PLAN_CACHE", str(tmp_path))
+    frames = torch.from_numpy(synth.synthetic_frames(2, 160, 160, seed=4)).cuda()
+    m1 = YOLO.from_state_dict("yolov8n", v8n[1], batch_chunk=2)
+    r1 = m1.predict(frames, imgsz=160)
+    i1 = m1.plan_info()
+    files = glob.glob(str(tmp_path / "*.plan"))
+    assert i1["plan_source"] == "tuned" and len(files) == 1 and i1["launches_per_pass"] > 20 and i1["activation_bytes"] > 0
+    stamp = os.stat(files[0]).st_mtime_ns
+    m2 = YOLO.from_state_dict("yolov8n", v8n[1], batch_chunk=2)
+    r2 = m2.predict(frames, imgsz=160)
+    i2 = m2.plan_info()
+    assert i2["plan_source"] == "file" and i2["plan_hash"] == i1["plan_hash"] and os.stat(files[0]).st_mtime_ns == stamp
+    for a, b in zip(r1, r2):
+        np.testing.assert_array_equal(a.boxes.data.numpy(), b.boxes.data.numpy())
+    # a stale file (other fingerprint: another build, GPU or knob setting) is not trusted
+    lines = open(files[0]).read().split("\n")
+    head = lines[0].split()
+    head[2] = f"{int(head[2], 16) ^ 1:x}"
+    open(files[0], "w").write("\n".join([" ".join(head)] + lines[1:]))
+    m3 = YOLO.from_state_dict("yolov8n", v8n[1], batch_chunk=2)
+    m3.predict(frames, imgsz=160)
+    assert m3.plan_info()["plan_source"] == "tuned"

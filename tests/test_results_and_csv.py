@@ -167,3 +167,28 @@ def test_image_directory_capture_decodes_bgr_frames(tmp_path):
     Image.fromarray(frames[0][..., ::-1]).save(jpg / "0001.jpg", quality=95)
     ok, f = P.open_capture(str(jpg)).read()
     assert ok and f.shape == (24, 32, 3)                                          # JPEG: lossy, shape and layout only
+
+
+def test_image_directory_capture_orders_unpadded_frame_names_numerically(tmp_path):
+    """frame dumps named 1.jpg .. 12.jpg (no zero padding) must be read as 1, 2, ..., 12 -- a plain string sort would give
+    1, 10, 11, 12, 2, ... and label the CSV rows with the wrong CAP_PROP_POS_FRAMES"""
+    from PIL import Image
+    from cvsd_amd import preprocess_driver as P
+    clip = tmp_path / "clip"
+    clip.mkdir()
+    for k in range(1, 13):
+        Image.fromarray(np.full((8, 8, 3), k, dtype=np.uint8)).save(clip / f"{k}.png")
+    cap = P.open_capture(str(clip))
+    got = []
+    while True:
+        ok, f = cap.read()
+        if not ok:
+            break
+        got.append(int(f[0, 0, 0]))
+    assert got == list(range(1, 13))
+    mixed = tmp_path / "mixed"
+    mixed.mkdir()
+    for name, v in (("frame_10.png", 10), ("frame_9.png", 9), ("frame_100.png", 100), ("frame_0011.png", 11)):
+        Image.fromarray(np.full((8, 8, 3), v, dtype=np.uint8)).save(mixed / name)
+    cap = P.open_capture(str(mixed))
+    assert [int(cap.read()[1][0, 0, 0]) for _ in range(4)] == [9, 10, 11, 100]
