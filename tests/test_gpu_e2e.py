@@ -258,15 +258,15 @@ def test_shape_switching_reuses_tuning_and_stays_exact(v8n):
     ra = [r.boxes.data.numpy().copy() for r in m.predict(a, conf=0.1, imgsz=160)]
     rb = [r.boxes.data.numpy().copy() for r in m.predict(b, conf=0.1, imgsz=96)]
     seen = {}
-    for _ in range(3):
+    for it in range(3):
         for got, want in zip(m.predict(a, conf=0.1, imgsz=160), ra):
             np.testing.assert_array_equal(got.boxes.data.numpy(), want)
         for got, want in zip(m.predict(b, conf=0.1, imgsz=96), rb):
             np.testing.assert_array_equal(got.boxes.data.numpy(), want)
         np.testing.assert_array_equal(m.predict(a[:1], conf=0.1, imgsz=160)[0].boxes.data.numpy(), ra[0])
         # a shape seen before is served from this process's memory (never re-timed): same plan hash, source "memory"
-        info = m.plan_info()
-        assert info["plan_source"] == "memory"
+        info = m.plan_info()                       # of the (1 frame, 128x160) shape, first met in the first round
+        assert info["plan_source"] in (("memory",) if it else ("tuned", "file"))
         assert seen.setdefault("hash", info["plan_hash"]) == info["plan_hash"]
 
 
