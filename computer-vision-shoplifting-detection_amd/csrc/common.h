@@ -82,6 +82,26 @@ struct ConvKArgs {
 // A planned launch: kernel instance, grid, LDS bytes and kernel arguments.  Planning (tile / wave-arrangement
 // search) is done once per (op, shape) by the engine; run_conv only enqueues.
 struct ConvLaunch { const void* fn; unsigned grid_x, grid_y; size_t lds; ConvKArgs a; int CT, WP; double flops; int threads; int version; int PT; };
+// ---- grouped launches (conv_f32_group.hip) ---------------------------------------------------------------------------
+// Independent convs of one depth of the op DAG (the box / class / keypoint branches of the head levels beside the neck's own
+// chain) run as ONE grid: block ranges [base[m], base[m + 1]) belong to member m, which runs its own tuned kernel instance
+// (`kind` = index into a fixed menu of conv_igemm_f32 / conv_splitk_f32 / conv1x1_stream_f32 instances) on its own arguments.
+// In the latency-bound regime (a few frames per pass) a launch costs 5-15 us whatever it computes and leaves most CUs idle; a
+// group costs max(members) instead of sum(members) -- what several streams would buy without their cross-queue event waits.
+constexpr int kGroupMax = 4;
+struct GroupKArgs {
+    int n;
+    unsigned base[kGroupMax + 1];      // first block of member m (multiples of 8: the XCD-aware work order stays valid per member)
+    int kind[kGroupMax];
+    unsigned gx[kGroupMax], gy[kGroupMax];
+    ConvKArgs a[kGroupMax];
+};
+struct GroupLaunch { GroupKArgs k; unsigned grid; size_t lds; int n_members; int op[kGroupMax]; void* dev; };   // dev: device copy of k (owner: the engine)
+// menu index of a planned launch, or -1 when its kernel instance is not part of the group kernel
+int group_kind(const ConvLaunch& l, int ks, int stride);
+const char* plan_group(const std::vector<ConvLaunch>& members, const std::vector<int>& kinds, GroupLaunch* out);
+const char* run_group(const GroupLaunch& g, hipStream_t st);
+
 const char* plan_conv(const ConvArgs& c, ConvLaunch* out);
 const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out);   // best static guess first
 const char* run_conv(const ConvLaunch& l, hipStream_t st);
@@ -161,31 +181,38 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 #ifndef MI355_XCD_REMAP
 #define MI355_XCD_REMAP 1
 #endif
+// A kernel body may run as a MEMBER of a grouped launch (conv_f32_group.hip: independent convs of one DAG depth in one grid):
+// its block coordinates are then virtual -- (x, y) inside a (gx, gy) grid of its own, `lin0` = the launch-wide linear id of
+// the member's first block (a multiple of 8, so that "blocks b and b + 8 share an XCD" still holds inside the member).
+struct BlockId { unsigned x, y, gx, gy; };
+#define MI355_BLOCK_ID() (::mi355::BlockId{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y})
 // the same with the division by gridDim.y on the scalar unit (fd = make_fastdiv(gridDim.y); total blocks < 2^24)
-__device__ __forceinline__ void xcd_work_item(int& tile, int& cgroup, FastDiv fd) {
+__device__ __forceinline__ void xcd_work_item(int& tile, int& cgroup, FastDiv fd, const BlockId& bid) {
 #if MI355_XCD_REMAP
-    const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy;
-    const unsigned id = blockIdx.y * gx + blockIdx.x;
+    const unsigned gx = bid.gx, gy = bid.gy, n = gx * gy;
+    const unsigned id = bid.y * gx + bid.x;
     const unsigned q = n >> 3, r = n & 7, x = id & 7;
     const unsigned logical = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
     tile = (int)fastdiv(logical, fd);
     cgroup = (int)(logical - (unsigned)tile * gy);
 #else
-    tile = (int)blockIdx.x; cgroup = (int)blockIdx.y;
+    tile = (int)bid.x; cgroup = (int)bid.y;
 #endif
 }
-__device__ __forceinline__ void xcd_work_item(int& tile, int& cgroup) {
+__device__ __forceinline__ void xcd_work_item(int& tile, int& cgroup, const BlockId& bid) {
 #if MI355_XCD_REMAP
-    const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy;
-    const unsigned id = blockIdx.y * gx + blockIdx.x;
+    const unsigned gx = bid.gx, gy = bid.gy, n = gx * gy;
+    const unsigned id = bid.y * gx + bid.x;
     const unsigned q = n >> 3, r = n & 7, x = id & 7;
     const unsigned logical = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
     tile = (int)(logical / gy);
     cgroup = (int)(logical - (unsigned)tile * gy);
 #else
-    tile = (int)blockIdx.x; cgroup = (int)blockIdx.y;
+    tile = (int)bid.x; cgroup = (int)bid.y;
 #endif
 }
+__device__ __forceinline__ void xcd_work_item(int& tile, int& cgroup, FastDiv fd) { xcd_work_item(tile, cgroup, fd, MI355_BLOCK_ID()); }
+__device__ __forceinline__ void xcd_work_item(int& tile, int& cgroup) { xcd_work_item(tile, cgroup, MI355_BLOCK_ID()); }
 #endif
 
 }  // namespace mi355

@@ -135,8 +135,7 @@ __device__ __forceinline__ void store_tile(f32x4 v, const float* bias, int act, 
                                  // tools/ab_build.sh: 1 -> 4 costs a 12-byte spill outside the loop, buys 2-3 % on the stride-2 layers, 0-1 % elsewhere)
 #endif
 template <int KS, int STRIDE, int PT, int CT, int WP, bool F2 = false>
-__global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : PT * CT == 8 ? MI355_V1_MINWAVES8 : PT * CT >= 15 ? MI355_V1_MINWAVES16 : 1)) void conv_igemm_f32(ConvKArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void conv_igemm_f32_body(const ConvKArgs& a, float* lds, const BlockId& bid) {
     constexpr int WC = 4 / WP;
     constexpr int TAPS = KS * KS;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -150,7 +149,7 @@ __global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : PT * CT ==
     // tile decomposition on the scalar unit (FastDiv), per-lane products as 24-bit multiplies: the prologue's integer
     // divisions and 32/64-bit multiplies were ~50 slow vector instructions per block
     int t, cgrp0;
-    xcd_work_item(t, cgrp0, a.fd_gy);
+    xcd_work_item(t, cgrp0, a.fd_gy, bid);
     const int tq = (int)fastdiv((unsigned)t, a.fd_tx), tx = t - tq * a.tiles_x;
     const int b = (int)fastdiv((unsigned)tq, a.fd_ty), ty = tq - b * a.tiles_y;
     const int oy0 = ty * a.TH, ox0 = tx * a.TW;
@@ -410,6 +409,12 @@ __global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : PT * CT ==
     }
 }
 
+template <int KS, int STRIDE, int PT, int CT, int WP, bool F2 = false>
+__global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : PT * CT == 8 ? MI355_V1_MINWAVES8 : PT * CT >= 15 ? MI355_V1_MINWAVES16 : 1)) void conv_igemm_f32(ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    conv_igemm_f32_body<KS, STRIDE, PT, CT, WP, F2>(a, lds, MI355_BLOCK_ID());
+}
+
 // ---------------------------------------------------------------------------------------------- v6 (3x3, split K)
 // Latency-bound launches (batch 1: a 20x20 map is 25 pixel tiles, a 3x3 conv over 256 channels a chain of 576 MFMAs per
 // accumulator): the four waves of a block work on the SAME PT x CT tiles and split the 16-channel blocks between them
@@ -418,14 +423,13 @@ __global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : PT * CT ==
 // go to LDS (1 KiB per tile and block) and are then added in ascending block order, exactly as the one-wave kernels do in
 // registers.  LDS = [halo tile of one chunk | cib x CT x PT partial tiles].
 template <int KS, int STRIDE, int PT, int CT>
-__global__ __launch_bounds__(256) void conv_splitk_f32(ConvKArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void conv_splitk_f32_body(const ConvKArgs& a, float* lds, const BlockId& bid) {
     constexpr int TAPS = KS * KS;
     static_assert(TAPS == 9, "split-K kernel is written for 3x3 convs");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform by construction: lets the K offsets live in SGPRs
     int t, cgrp0;
-    xcd_work_item(t, cgrp0);
+    xcd_work_item(t, cgrp0, bid);
     const int tx = t % a.tiles_x; t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     const int b = t / a.tiles_y;
@@ -564,6 +568,12 @@ __global__ __launch_bounds__(256) void conv_splitk_f32(ConvKArgs a) {
     }
 }
 
+template <int KS, int STRIDE, int PT, int CT>
+__global__ __launch_bounds__(256) void conv_splitk_f32(ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    conv_splitk_f32_body<KS, STRIDE, PT, CT>(a, lds, MI355_BLOCK_ID());
+}
+
 // ---------------------------------------------------------------------------------------------- v3 (1x1 only)
 // Pointwise convs have no tap reuse, so staging pixels through LDS buys nothing: here every wave streams its pixel
 // fragments straight from global memory into the MFMA B-operand layout (lane (p, g) reads the 16 bytes of channels
@@ -571,14 +581,14 @@ __global__ __launch_bounds__(256) void conv_splitk_f32(ConvKArgs a) {
 // pixels (HBM latency) and weights (L2 latency).  No LDS, no barriers: waves drift apart and overlap each other's
 // epilogues.  Same canonical accumulation order as v1 (per 16-channel block a chain from +0; partials summed in block order).
 template <int PT, int CT>
-__global__ __launch_bounds__(256, (PT * CT >= 16 ? 2 : PT * CT >= 8 ? 3 : 1)) void conv1x1_stream_f32(ConvKArgs a) {
+__device__ __forceinline__ void conv1x1_stream_f32_body(const ConvKArgs& a, const BlockId& bid) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: tile bases and weight offsets stay scalar
     const int g = lane >> 4;
     const int total = a.Wout;                                        // flattened pixels (Hout == 1)
     int pblk, cgrp0;
-    xcd_work_item(pblk, cgrp0);
+    xcd_work_item(pblk, cgrp0, bid);
     const int ct0 = cgrp0 * CT;
     // Every access goes through a buffer descriptor (32-bit lane offset + scalar offset, no 64-bit vector arithmetic; the fp32
     // matrix instructions share issue cycles with the vector ALU): source / destination / residual descriptors start at THIS
@@ -682,6 +692,11 @@ __global__ __launch_bounds__(256, (PT * CT >= 16 ? 2 : PT * CT >= 8 ? 3 : 1)) vo
             }
         }
     }
+}
+
+template <int PT, int CT>
+__global__ __launch_bounds__(256, (PT * CT >= 16 ? 2 : PT * CT >= 8 ? 3 : 1)) void conv1x1_stream_f32(ConvKArgs a) {
+    conv1x1_stream_f32_body<PT, CT>(a, MI355_BLOCK_ID());
 }
 
 // ---------------------------------------------------------------------------------------------- v4 (1x1 only)

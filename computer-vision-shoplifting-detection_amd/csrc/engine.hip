@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -160,6 +161,17 @@ struct mi355_yolo {
     std::vector<std::vector<int>> op_xdeps;   // producers on other streams
     std::vector<char> op_signals;             // op has a consumer on another stream (or is a head output: decode joins on it)
     std::vector<int> leaf_ops;                // ops that write the head-level buffers
+    std::vector<std::vector<int>> deps;       // RAW producers of every op (program order indices)
+    // Grouped launches (conv_f32_group.hip), the single-stream regime's answer to the idle chip: the launched ops are list-
+    // scheduled into STEPS (all ops of a step are mutually independent: every producer ran in an earlier step); the conv ops
+    // of a step whose tuned kernel is on the group kernel's menu run as ONE grid when the stopwatch says that beats the
+    // separate launches.  group_sel[i] >= 0: op i runs inside its step's group with plan group_sel[i] of its candidate list
+    // (fused list when its pointwise consumer runs inside it).  MI355_GROUPS=0 turns it off.
+    struct Step { std::vector<int> singles; int group = -1; };
+    std::vector<Step> steps;
+    std::vector<GroupLaunch> groups;
+    std::vector<int> group_sel;
+    int use_groups = 1, group_max_batch = 5;
     float* pred = nullptr; float2* best = nullptr; unsigned long long* keys = nullptr;
     int A = 0, Apow2 = 0;
     uint8_t* lbox = nullptr;            // letterboxed frames of one chunk (also the stable stem input of the graph path)
@@ -193,6 +205,8 @@ void mi355_yolo::free_shape() {
     graphs.clear();
     for (float* p : dbuf) if (p) (void)hipFree(p);
     dbuf.clear(); dbuf_cs.clear(); dbuf_es.clear(); plans.clear();
+    for (auto& g : groups) if (g.dev) (void)hipFree(g.dev);
+    groups.clear(); steps.clear();
     if (pred) (void)hipFree(pred); if (best) (void)hipFree(best); if (keys) (void)hipFree(keys);
     if (lbox) (void)hipFree(lbox);
     pred = nullptr; best = nullptr; keys = nullptr; lbox = nullptr;
@@ -375,6 +389,8 @@ static int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
     if (const char* e = getenv("MI355_STREAMS")) h->n_streams = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("MI355_STREAMS_MAX_BATCH")) h->streams_max_batch = atoi(e);
     if (const char* e = getenv("MI355_STREAMS_MIN_BATCH")) h->streams_min_batch = atoi(e);
+    if (const char* e = getenv("MI355_GROUPS")) h->use_groups = atoi(e);
+    if (const char* e = getenv("MI355_GROUP_MAX_BATCH")) h->group_max_batch = atoi(e);
     return build_schedule(h);
 }
 
@@ -401,6 +417,7 @@ static int build_schedule(mi355_yolo* h) {
         std::sort(deps[i].begin(), deps[i].end());
         deps[i].erase(std::unique(deps[i].begin(), deps[i].end()), deps[i].end());
     }
+    h->deps = deps;
     std::vector<int> depth(n, 0);
     for (int i = 0; i < n; ++i)
         for (int d : deps[i]) depth[i] = std::max(depth[i], depth[d] + 1);
@@ -478,7 +495,7 @@ static std::string plan_cache_path(const mi355_yolo* h, int nb, int Hl, int Wl) 
 constexpr int kUpBase = 10000;       // chosen[i] >= kUpBase: the conv reads the upsample kernel's output with plan chosen[i] - kUpBase
 
 static bool load_plan_choices(const mi355_yolo* h, int nb, int Hl, int Wl, const std::vector<int>& n_cands, unsigned long long fp,
-                              std::vector<int>* chosen) {
+                              std::vector<int>* chosen, std::vector<int>* gsel) {
     const std::string path = plan_cache_path(h, nb, Hl, Wl);
     if (path.empty()) return false;
     FILE* f = std::fopen(path.c_str(), "r");
@@ -487,29 +504,30 @@ static bool load_plan_choices(const mi355_yolo* h, int nb, int Hl, int Wl, const
     int n = 0;
     unsigned long long got_fp = 0;
     bool ok = std::fscanf(f, "%63s %d %llx", ver, &n, &got_fp) == 3 && std::strcmp(ver, kPlanVersion) == 0 && n == (int)n_cands.size() && got_fp == fp;
-    std::vector<int> got(n_cands.size(), 0);
+    std::vector<int> got(n_cands.size(), 0), gg(n_cands.size(), -1);
     for (size_t i = 0; ok && i < n_cands.size(); ++i) {
-        int c = 0, nc = 0;
+        int c = 0, nc = 0, g = -1;
         // nc = plain + 1000 * fused-pointwise + 1000000 * behind-the-upsample-kernel list sizes.  c in [0, 10000): index into the
         // plain list; c < 0: fused plan -(c + 1); c >= 10000: plan c - 10000 of the list that reads the upsample kernel's output
-        ok = std::fscanf(f, "%d/%d", &c, &nc) == 2 && nc == n_cands[i] &&
+        // third field: the plan this op runs with INSIDE its step's grouped launch (index into the list `c` selects from), or -1
+        ok = std::fscanf(f, "%d/%d/%d", &c, &nc, &g) == 3 && nc == n_cands[i] && g >= -1 && g < 1000 &&
              (c >= kUpBase ? (c - kUpBase < nc / 1000000) : c >= 0 ? (c < nc % 1000 || nc == 0) : (-c - 1 < (nc / 1000) % 1000));
-        got[i] = c;
+        got[i] = c; gg[i] = g;
     }
     std::fclose(f);
-    if (ok) *chosen = got;
+    if (ok) { *chosen = got; *gsel = gg; }
     return ok;
 }
 
 static void save_plan_choices(const mi355_yolo* h, int nb, int Hl, int Wl, const std::vector<int>& n_cands, unsigned long long fp,
-                              const std::vector<int>& chosen) {
+                              const std::vector<int>& chosen, const std::vector<int>& gsel) {
     const std::string path = plan_cache_path(h, nb, Hl, Wl);
     if (path.empty()) return;
     const std::string tmp = path + "." + std::to_string((long)getpid());
     FILE* f = std::fopen(tmp.c_str(), "w");
     if (!f) return;
     std::fprintf(f, "%s %zu %llx\n", kPlanVersion, n_cands.size(), fp);
-    for (size_t i = 0; i < n_cands.size(); ++i) std::fprintf(f, "%d/%d\n", chosen[i], n_cands[i]);
+    for (size_t i = 0; i < n_cands.size(); ++i) std::fprintf(f, "%d/%d/%d\n", chosen[i], n_cands[i], gsel[i]);
     std::fclose(f);
     if (std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());   // atomic: ranks may race
 }
@@ -612,9 +630,14 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
     }
     // pass 2: choices -- this process's memory, then the plan file, then the stopwatch.  chosen[i] >= 0: index into the plain
     // list; chosen[i] = -(k + 1): fused plan k (the pointwise consumer then runs inside this launch and is skipped).
-    std::vector<int> chosen(h->ops.size(), 0);
-    bool have = false;
-    for (const auto& t : h->tuned) if (t.first == shape_key) { chosen = t.second; have = true; }
+    const size_t n_ops = h->ops.size();
+    std::vector<int> chosen(n_ops, 0), gsel(n_ops, -1);
+    bool have = false, have_groups = false;       // have_groups: gsel is a decision (memory / file), not the initial "none"
+    for (const auto& t : h->tuned)
+        if (t.first == shape_key) {
+            chosen.assign(t.second.begin(), t.second.begin() + n_ops); gsel.assign(t.second.begin() + n_ops, t.second.end());
+            have = have_groups = true;
+        }
     unsigned long long fp = 1469598103934665603ull;
     {
         hipDeviceProp_t prop{};
@@ -625,7 +648,7 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
         for (size_t i = 0; i < h->ops.size(); ++i) { fp = cand_fingerprint(fp, cands[i]); fp = cand_fingerprint(fp, cands_f[i]); fp = cand_fingerprint(fp, cands_u[i]); }
     }
     h->plan_source = have ? 1 : 0;          // 1 = this process's memory
-    if (!have && h->autotune) { have = load_plan_choices(h, nb, Hl, Wl, n_cands, fp, &chosen); if (have) h->plan_source = 2; }
+    if (!have && h->autotune) { have = load_plan_choices(h, nb, Hl, Wl, n_cands, fp, &chosen, &gsel); if (have) { h->plan_source = 2; have_groups = true; } }
     auto run_upsample = [&](int ui) -> int {
         const FileOp& u = h->ops[ui];
         const int sd_in = h->bufs[u.src_buf].stride_div, dv = h->dbuf_es[u.src_buf] == 2 ? 2 : 1;
@@ -708,8 +731,6 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                                       chosen[i] < 0 ? "fused" : "separate");
             }
         }
-        h->tuned.push_back({shape_key, chosen});
-        save_plan_choices(h, nb, Hl, Wl, n_cands, fp, chosen);
         have = true;
         h->plan_source = 3;
     }
@@ -726,15 +747,145 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                 h->plans[i] = cands[i][chosen[i]];
             }
         }
+    }
+    // ---- grouped launches of the single-stream regime: list-schedule the launched ops into steps, then decide per step ----
+    for (auto& g : h->groups) if (g.dev) (void)hipFree(g.dev);
+    h->groups.clear(); h->steps.clear();
+    h->group_sel.assign(n_ops, -1);
+    const bool stepwise = h->use_groups && !h->half && nb <= h->group_max_batch && nb < h->streams_min_batch;
+    auto launched = [&](int i) { return !(h->ops[i].type == OP_UPSAMPLE && h->fused_away[i]) && !h->skip_op[i]; };
+    auto list_of = [&](int i) -> const std::vector<ConvLaunch>& {      // the candidate list op i's current plan was taken from
+        return (h->fuse2[i] >= 0 && h->skip_op[h->fuse2[i]]) ? cands_f[i] : chosen[i] >= kUpBase ? cands_u[i] : cands[i];
+    };
+    if (stepwise) {
+        // avail[i] = step after which op i's output exists; an op is ready when all its producers are available
+        const int n = (int)n_ops;
+        std::vector<int> avail(n, -1), producer_of(n, -1);
+        for (int i = 0; i < n; ++i) if (h->fuse2[i] >= 0 && h->skip_op[h->fuse2[i]]) producer_of[h->fuse2[i]] = i;
+        std::vector<char> placed(n, 0);
+        int left = 0;
+        for (int i = 0; i < n; ++i) left += launched(i);
+        // data of an op that is not launched itself: inside its producer's launch (fused pointwise conv) or never materialised
+        // (upsample read by its consumer straight from the half-size map: available when the upsample's own producers are)
+        std::function<int(int)> avail_of = [&](int d) -> int {
+            if (launched(d)) return placed[d] ? avail[d] : 1 << 30;
+            if (producer_of[d] >= 0) return placed[producer_of[d]] ? avail[producer_of[d]] : 1 << 30;
+            int a = -1;
+            for (int dd : h->deps[d]) a = std::max(a, avail_of(dd));
+            return a;
+        };
+        for (int step = 0; left > 0; ++step) {
+            mi355_yolo::Step st;
+            std::vector<int> now;
+            for (int i = 0; i < n; ++i) {
+                if (!launched(i) || placed[i]) continue;
+                int a = -1;
+                for (int d : h->deps[i]) a = std::max(a, avail_of(d));
+                if (a < step) now.push_back(i);
+            }
+            if (now.empty()) return fail(MI355_EFORMAT, "op program has a dependency cycle");
+            for (int i : now) { placed[i] = 1; avail[i] = step; --left; st.singles.push_back(i); }
+            h->steps.push_back(st);
+        }
+        if (!have_groups && have && h->autotune) {
+            // decide per step by the stopwatch: the convs whose kernel is on the group kernel's menu, as one grid, against
+            // the same convs launched one after the other with their individually best plans
+            for (auto& st : h->steps) {
+                struct Member { int op, sel; ConvLaunch l; int kind; float t_ind; };
+                std::vector<Member> mem;
+                for (int i : st.singles) {
+                    if (h->ops[i].type != OP_CONV) continue;
+                    const FileConv& c = h->convs[h->ops[i].conv];
+                    const std::vector<ConvLaunch>& list = list_of(i);
+                    Member m{i, -1, h->plans[i], group_kind(h->plans[i], (int)c.k, (int)c.s), 0.f};
+                    int k0 = 0;
+                    std::vector<ConvLaunch> one{h->plans[i]};
+                    int rc = time_list(one, c.name, &k0, &m.t_ind); if (rc) return rc;
+                    if (m.kind >= 0) {
+                        for (size_t k = 0; k < list.size(); ++k)
+                            if (list[k].fn == m.l.fn && list[k].grid_x == m.l.grid_x && list[k].grid_y == m.l.grid_y && list[k].lds == m.l.lds &&
+                                list[k].a.TW == m.l.a.TW && list[k].a.ck == m.l.a.ck && list[k].a.cgroups == m.l.a.cgroups) { m.sel = (int)k; break; }
+                    }
+                    if (m.sel < 0) {                 // the tuned kernel is not on the menu: the best plan that is
+                        std::vector<ConvLaunch> menu; std::vector<int> idx;
+                        for (size_t k = 0; k < list.size(); ++k)
+                            if (group_kind(list[k], (int)c.k, (int)c.s) >= 0) { menu.push_back(list[k]); idx.push_back((int)k); }
+                        if (menu.empty()) continue;
+                        int kb = 0; float tb = 0.f;
+                        rc = time_list(menu, c.name, &kb, &tb); if (rc) return rc;
+                        m.sel = idx[kb]; m.l = menu[kb]; m.kind = group_kind(m.l, (int)c.k, (int)c.s);
+                    }
+                    mem.push_back(m);
+                }
+                if (mem.size() < 2) continue;
+                std::sort(mem.begin(), mem.end(), [](const Member& a, const Member& b) { return a.t_ind > b.t_ind; });
+                if (mem.size() > (size_t)kGroupMax) mem.resize(kGroupMax);
+                std::vector<ConvLaunch> ls; std::vector<int> kinds; float t_sum = 0.f;
+                for (const Member& m : mem) { ls.push_back(m.l); kinds.push_back(m.kind); t_sum += m.t_ind; }
+                GroupLaunch g{};
+                if (plan_group(ls, kinds, &g) != nullptr) continue;
+                HIPCHK(hipMalloc(&g.dev, sizeof(GroupKArgs)));
+                HIPCHK(hipMemcpy(g.dev, &g.k, sizeof(GroupKArgs), hipMemcpyHostToDevice));
+                float t_grp = 1e30f;
+                for (int rep = 0; rep < 4; ++rep) {
+                    HIPCHK(hipEventRecord(h->ev0, h->stream));
+                    for (int j = 0; j < 8; ++j) KCHK(run_group(g, h->stream));
+                    HIPCHK(hipEventRecord(h->ev1, h->stream));
+                    HIPCHK(hipEventSynchronize(h->ev1));
+                    float t = 0.f;
+                    HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
+                    if (rep > 0) t_grp = std::min(t_grp, t / 8.0f);
+                }
+                (void)hipFree(g.dev);
+                if (tune_log) {
+                    fprintf(stderr, "[tune] group of %zu:", mem.size());
+                    for (const Member& m : mem) fprintf(stderr, " %s(%.1f us)", h->convs[h->ops[m.op].conv].name, m.t_ind * 1e3);
+                    fprintf(stderr, " : grouped %.1f us vs separate %.1f us -> %s\n", t_grp * 1e3, t_sum * 1e3, t_grp < 0.97f * t_sum ? "grouped" : "separate");
+                }
+                if (t_grp < 0.97f * t_sum)
+                    for (const Member& m : mem) gsel[m.op] = m.sel;
+            }
+            have_groups = true;
+        }
+        // materialise the decisions: members with a selection leave the step's single launches and form its group
+        for (auto& st : h->steps) {
+            std::vector<int> members, singles;
+            for (int i : st.singles) {
+                const bool ok = h->ops[i].type == OP_CONV && gsel[i] >= 0 && (size_t)gsel[i] < list_of(i).size() &&
+                                group_kind(list_of(i)[gsel[i]], (int)h->convs[h->ops[i].conv].k, (int)h->convs[h->ops[i].conv].s) >= 0;
+                (ok && members.size() < (size_t)kGroupMax ? members : singles).push_back(i);
+            }
+            if (members.size() < 2) continue;
+            std::vector<ConvLaunch> ls; std::vector<int> kinds;
+            for (int i : members) {
+                const FileConv& c = h->convs[h->ops[i].conv];
+                ls.push_back(list_of(i)[gsel[i]]); kinds.push_back(group_kind(ls.back(), (int)c.k, (int)c.s));
+            }
+            GroupLaunch g{};
+            if (plan_group(ls, kinds, &g) != nullptr) continue;
+            for (size_t m = 0; m < members.size(); ++m) { g.op[m] = members[m]; h->group_sel[members[m]] = gsel[members[m]]; }
+            HIPCHK(hipMalloc(&g.dev, sizeof(GroupKArgs)));
+            HIPCHK(hipMemcpy(g.dev, &g.k, sizeof(GroupKArgs), hipMemcpyHostToDevice));
+            st.singles = singles; st.group = (int)h->groups.size();
+            h->groups.push_back(g);
+        }
+    }
+    if (have) {
+        std::vector<int> both(chosen);
+        both.insert(both.end(), gsel.begin(), gsel.end());
         bool known = false;
-        for (const auto& t : h->tuned) known |= (t.first == shape_key);
-        if (!known) h->tuned.push_back({shape_key, chosen});
+        for (auto& t : h->tuned) if (t.first == shape_key) { t.second = both; known = true; }
+        if (!known) h->tuned.push_back({shape_key, both});
+        if (h->plan_source == 3) save_plan_choices(h, nb, Hl, Wl, n_cands, fp, chosen, gsel);
     }
     h->cur_nb = nb;
-    h->plan_hash = fnv1a(fp, chosen.data(), chosen.size() * sizeof(int));     // candidates + choices: identifies the launch sequence
+    h->plan_hash = fnv1a(fnv1a(fp, chosen.data(), chosen.size() * sizeof(int)), h->group_sel.data(), h->group_sel.size() * sizeof(int));   // candidates + choices: identifies the launch sequence
     h->plan_launches = 0;
-    for (size_t i = 0; i < h->ops.size(); ++i)
-        h->plan_launches += !(h->ops[i].type == OP_UPSAMPLE && h->fused_away[i]) && !h->skip_op[i];
+    if (!h->steps.empty()) {
+        for (const auto& st : h->steps) h->plan_launches += (int)st.singles.size() + (st.group >= 0);
+    } else {
+        for (size_t i = 0; i < h->ops.size(); ++i) h->plan_launches += launched((int)i);
+    }
     if (getenv("MI355_SCHED_LOG")) {      // launch order of a pass for tools/layer_report.py: position, op index, stream, launched
         for (size_t pos = 0; pos < h->sched_order.size(); ++pos) {
             const int idx = h->sched_order[pos];
@@ -875,7 +1026,17 @@ static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, c
     // several streams along the dependency DAG (profiling keeps the single in-order stream; under hipGraph capture the
     // event waits fork the aux streams into the capture and the decode join brings them back)
     const bool multi = h->n_streams > 1 && !h->profiling && nb <= h->streams_max_batch && nb >= h->streams_min_batch;
-    if (!multi) {
+    if (!multi && !h->steps.empty() && nb == h->cur_nb) {
+        // single in-order stream, step by step: the ops of a step are mutually independent; its grouped convs are one grid
+        for (const auto& stp : h->steps) {
+            for (int i : stp.singles) { const int rc = launch_op((size_t)i, h->stream); if (rc) return rc; }
+            if (stp.group >= 0) {
+                if (pf.begin(K_CONV)) return fail(MI355_EHIP, "event");
+                KCHK(run_group(h->groups[stp.group], h->stream));
+                pf.end();
+            }
+        }
+    } else if (!multi) {
         for (size_t i = 0; i < h->ops.size(); ++i) { const int rc = launch_op(i, h->stream); if (rc) return rc; }
     } else {
         for (int idx : h->sched_order) {
