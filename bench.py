@@ -371,15 +371,18 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dry = os.environ.get("BENCH_DRYRUN_ONE_GPU") == "1"
+    # device_count() does not initialise the GPU: a rank without a GPU of its own leaves before it opens one
+    if torch.cuda.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the hot path)")
+    if not dry and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible (--gpus {args.gpus})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the hot path)")
     # BENCH_DRYRUN_ONE_GPU=1 (tests only): all ranks share cuda:0 and the collectives run over gloo, to rehearse the
     # N > 1 code path on a one-GPU box.  The real launch is one rank per GPU over RCCL (backend "nccl").
-    dry = os.environ.get("BENCH_DRYRUN_ONE_GPU") == "1"
     if dry:
         local_rank = 0
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible (--gpus {args.gpus})")
     torch.cuda.set_device(local_rank)
     backend = None
     if world > 1:

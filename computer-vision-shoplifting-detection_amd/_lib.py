@@ -61,7 +61,9 @@ SIGNATURES = {
     "mi355_yolo_sync": (C.c_int, [C.c_void_p]),
     "mi355_yolo_raw_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       _i32p, _i32p]),
-    "mi355_yolo_plan_info": (C.c_int, [C.c_void_p, _P(C.c_ulonglong), _i32p, _i32p, _P(C.c_longlong)]),
+    "mi355_yolo_plan_info": (C.c_int, [C.c_void_p, _P(C.c_ulonglong), _i32p, _i32p, _P(C.c_longlong), _P(C.c_longlong)]),
+    "mi355_memory_plan": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P(C.c_longlong),
+                                    _P(C.c_longlong), C.c_int, _i32p, _P(C.c_longlong), _P(C.c_longlong)]),
     "mi355_yolo_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mi355_yolo_last_timing": (C.c_int, [C.c_void_p, _P(Timing)]),
     "mi355_op_conv2d": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -63,6 +63,7 @@ struct Geometry {
 };
 
 static double py_round(double x) { return std::nearbyint(x); }   // round-half-even, like Python's round()
+static size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
 static Geometry make_geometry(int h0, int w0, int imgsz) {
     Geometry g{};
@@ -131,7 +132,12 @@ struct mi355_yolo {
     int cur_nb = 0, cur_H = 0, cur_W = 0, alloc_nb = 0;
     long long act_bytes = 0;            // bytes of activation buffers currently allocated
     unsigned long long model_hash = 0;  // FNV-1a of the .mi355w image: key of the persisted plan choices
-    std::vector<float*> dbuf;           // activation buffers (fp32, or fp16 bytes behind a float* when `half`)
+    std::vector<float*> dbuf;           // activation buffers (fp32, or fp16 bytes behind a float* when `half`): views into `arena`
+    bool host_only = false;             // mi355_memory_plan: program analysis without a device (no weights uploaded, nothing launched)
+    char* arena = nullptr;              // ONE allocation; buffers whose lifetimes cannot overlap under ANY legal schedule share bytes
+    int mem_reuse = 1;                  // MI355_MEM_REUSE=0: every buffer gets bytes of its own (the round-1/2 layout)
+    long long act_bytes_noreuse = 0;    // what the same shape takes without sharing (reported beside act_bytes)
+    std::vector<std::vector<unsigned long long>> anc;   // anc[i] = bitset over ops: RAW ancestors of op i (transitive)
     std::vector<int> dbuf_cs;           // pixel stride in ELEMENTS of the buffer's dtype
     std::vector<int> dbuf_es;           // element size in bytes: 4, or 2 for the fp16 buffers of the half=True path
     bool half = false;                  // opts.half: fp16 storage of activations / weights, fp32 arithmetic (conv_igemm_f16.hip)
@@ -203,7 +209,8 @@ struct mi355_yolo {
 void mi355_yolo::free_shape() {
     for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
     graphs.clear();
-    for (float* p : dbuf) if (p) (void)hipFree(p);
+    if (arena) (void)hipFree(arena);
+    arena = nullptr;
     dbuf.clear(); dbuf_cs.clear(); dbuf_es.clear(); plans.clear();
     for (auto& g : groups) if (g.dev) (void)hipFree(g.dev);
     groups.clear(); steps.clear();
@@ -309,6 +316,7 @@ static int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
         if (c.w_off + wn * 4 > H.data_bytes || c.b_off + (size_t)c.cout * 4 > H.data_bytes) return fail(MI355_EFORMAT, "tensor outside the data region");
         const float* w = (const float*)(data + c.w_off);
         const float* b = (const float*)(data + c.b_off);
+        if (h->host_only) continue;
         DevConv& d = h->dconv[i];
         const int bn = round_up((int)c.cout, 16);
         tmp.assign(bn, 0.f);
@@ -380,16 +388,19 @@ static int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
             h->fuse2[i] = reader;
         }
     }
-    float lut[256];
-    for (int i = 0; i < 256; ++i) lut[i] = (float)i / 255.0f;     // im /= 255 (IEEE fp32 division)
-    HIPCHK(hipMalloc(&h->lut, sizeof(lut)));
-    HIPCHK(hipMemcpy(h->lut, lut, sizeof(lut), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&h->zeros, 256));
-    HIPCHK(hipMemset(h->zeros, 0, 256));
+    if (!h->host_only) {
+        float lut[256];
+        for (int i = 0; i < 256; ++i) lut[i] = (float)i / 255.0f;     // im /= 255 (IEEE fp32 division)
+        HIPCHK(hipMalloc(&h->lut, sizeof(lut)));
+        HIPCHK(hipMemcpy(h->lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc(&h->zeros, 256));
+        HIPCHK(hipMemset(h->zeros, 0, 256));
+    }
     if (const char* e = getenv("MI355_STREAMS")) h->n_streams = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("MI355_STREAMS_MAX_BATCH")) h->streams_max_batch = atoi(e);
     if (const char* e = getenv("MI355_STREAMS_MIN_BATCH")) h->streams_min_batch = atoi(e);
     if (const char* e = getenv("MI355_GROUPS")) h->use_groups = atoi(e);
+    if (const char* e = getenv("MI355_MEM_REUSE")) h->mem_reuse = atoi(e);
     if (const char* e = getenv("MI355_GROUP_MAX_BATCH")) h->group_max_batch = atoi(e);
     return build_schedule(h);
 }
@@ -418,6 +429,15 @@ static int build_schedule(mi355_yolo* h) {
         deps[i].erase(std::unique(deps[i].begin(), deps[i].end()), deps[i].end());
     }
     h->deps = deps;
+    {   // transitive RAW ancestors (program order is a topological order: producers precede their readers)
+        const size_t words = ((size_t)n + 63) / 64;
+        h->anc.assign(n, std::vector<unsigned long long>(words, 0ull));
+        for (int i = 0; i < n; ++i)
+            for (int d : deps[i]) {
+                h->anc[i][d >> 6] |= 1ull << (d & 63);
+                for (size_t w = 0; w < words; ++w) h->anc[i][w] |= h->anc[d][w];
+            }
+    }
     std::vector<int> depth(n, 0);
     for (int i = 0; i < n; ++i)
         for (int d : deps[i]) depth[i] = std::max(depth[i], depth[d] + 1);
@@ -446,6 +466,7 @@ static int build_schedule(mi355_yolo* h) {
             if (h->op_stream[d] != h->op_stream[i]) { h->op_xdeps[i].push_back(d); h->op_signals[d] = 1; }
     for (int l : h->leaf_ops) if (h->op_stream[l] != 0) h->op_signals[l] = 1;
     h->op_done.assign(n, nullptr);
+    if (h->host_only) return MI355_OK;
     for (int i = 0; i < n; ++i)
         if (h->op_signals[i]) HIPCHK(hipEventCreateWithFlags(&h->op_done[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -532,6 +553,74 @@ static void save_plan_choices(const mi355_yolo* h, int nb, int Hl, int Wl, const
     if (std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());   // atomic: ranks may race
 }
 
+// Liveness-based placement of the activation buffers in ONE arena (host arithmetic only).  Fills h->dbuf_cs / dbuf_es.
+static void plan_memory(mi355_yolo* h, int nb, int Hl, int Wl, std::vector<size_t>* off_out, std::vector<size_t>* bytes_out,
+                        size_t* arena_out, size_t* plain_out) {
+    const size_t nbufs = h->bufs.size();
+    h->dbuf_cs.assign(nbufs, 0); h->dbuf_es.assign(nbufs, 4);
+    std::vector<size_t> bytes(nbufs, 0);
+    std::vector<char> pinned(nbufs, 0);
+    for (size_t i = 0; i < nbufs; ++i) {
+        // half=True: every buffer holds fp16 except the head outputs (raw box / class / keypoint logits), which the
+        // final 1x1 convs write in fp32 for the decode kernel
+        bool is_head = false;
+        for (const FileLevel& lv : h->levels) is_head |= (lv.buf == i);
+        const int es = (h->half && !is_head) ? 2 : 4;
+        const int cs = round_up((int)h->bufs[i].channels, 16 / es);
+        h->dbuf_es[i] = es; h->dbuf_cs[i] = cs;
+        bytes[i] = round_up_sz((size_t)nb * (Hl / h->bufs[i].stride_div) * (Wl / h->bufs[i].stride_div) * cs * es, 256);
+        // bytes of its own, forever: head outputs (the decode kernel reads them after the last op) and buffers with pad
+        // channels (cs > channels: zeroed once here, read -- times zero weights -- by the convs' padded k-blocks, never
+        // written: another tensor's bits there could be NaN patterns)
+        pinned[i] = is_head || cs != (int)h->bufs[i].channels || !h->mem_reuse;
+    }
+    // ---- liveness-based placement.  A buffer's users = every op that reads or writes any of its channels (a conv that may
+    // read an upsample's SOURCE directly counts as a user of that source).  Buffer b may take bytes of buffer a iff EVERY
+    // user of a is a RAW ancestor of EVERY writer of b: then the write-after-read / write-after-write order between them is
+    // implied by the dependencies the schedulers already honour (streams along the DAG, steps, groups) -- no edge is added,
+    // no parallelism is lost, and the sharing is race-free under any schedule that respects RAW.
+    const int n_ops = (int)h->ops.size();
+    std::vector<std::vector<int>> users(nbufs), writers(nbufs);
+    for (int i = 0; i < n_ops; ++i) {
+        const FileOp& o = h->ops[i];
+        auto use = [&](int b) { if (b >= 0 && (users[b].empty() || users[b].back() != i)) users[b].push_back(i); };
+        if (o.type != OP_STEM) use(o.src_buf);
+        if (o.res_buf >= 0) use(o.res_buf);
+        use(o.dst_buf); writers[o.dst_buf].push_back(i);
+        if (h->fuse_up[i] >= 0) use(h->ops[h->fuse_up[i]].src_buf);
+    }
+    auto is_anc = [&](int a, int of) { return (h->anc[of][a >> 6] >> (a & 63)) & 1ull; };
+    auto may_share = [&](size_t a, size_t b) {          // may b (written later) take a's bytes?
+        if (pinned[a] || pinned[b] || writers[b].empty() || users[a].empty()) return false;
+        for (int w : writers[b])
+            for (int u : users[a]) if (!is_anc(u, w)) return false;
+        return true;
+    };
+    std::vector<size_t> order(nbufs), off(nbufs, 0);
+    for (size_t i = 0; i < nbufs; ++i) order[i] = i;
+    auto first_w = [&](size_t b) { return writers[b].empty() ? 1 << 30 : writers[b].front(); };
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return first_w(a) < first_w(b); });
+    size_t arena_bytes = 0, plain_bytes = 0;
+    std::vector<size_t> placed;
+    for (size_t b : order) {
+        plain_bytes += bytes[b];
+        // lowest offset where b overlaps only buffers whose bytes it may take (first fit over the sorted conflict list)
+        std::vector<std::pair<size_t, size_t>> busy;
+        for (size_t a : placed) if (!may_share(a, b)) busy.push_back({off[a], off[a] + bytes[a]});
+        std::sort(busy.begin(), busy.end());
+        size_t at = 0;
+        for (const auto& iv : busy) {
+            if (at + bytes[b] <= iv.first) break;
+            at = std::max(at, iv.second);
+        }
+        off[b] = at; placed.push_back(b);
+        arena_bytes = std::max(arena_bytes, at + bytes[b]);
+    }
+    *off_out = off;
+    if (bytes_out) *bytes_out = bytes;
+    *arena_out = arena_bytes; *plain_out = plain_bytes;
+}
+
 static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
     if (h->cur_nb == nb && h->cur_H == Hl && h->cur_W == Wl) return MI355_OK;
     if ((Hl % 32) || (Wl % 32)) return fail(MI355_EINVAL, "letterboxed size must be a multiple of 32");
@@ -539,21 +628,14 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
     if (h->cur_H != Hl || h->cur_W != Wl || nb > h->alloc_nb) {
         // (re)allocate: a new letterboxed size, or more frames per pass than the buffers hold
         h->free_shape();
-        h->dbuf.assign(nbufs, nullptr); h->dbuf_cs.assign(nbufs, 0); h->dbuf_es.assign(nbufs, 4);
-        for (size_t i = 0; i < nbufs; ++i) {
-            // half=True: every buffer holds fp16 except the head outputs (raw box / class / keypoint logits), which the
-            // final 1x1 convs write in fp32 for the decode kernel
-            bool is_head = false;
-            for (const FileLevel& lv : h->levels) is_head |= (lv.buf == i);
-            const int es = (h->half && !is_head) ? 2 : 4;
-            const int cs = round_up((int)h->bufs[i].channels, 16 / es);
-            h->dbuf_es[i] = es;
-            const size_t bytes = (size_t)nb * (Hl / h->bufs[i].stride_div) * (Wl / h->bufs[i].stride_div) * cs * es;
-            HIPCHK(hipMalloc(&h->dbuf[i], bytes));
-            h->act_bytes += (long long)bytes;
-            HIPCHK(hipMemsetAsync(h->dbuf[i], 0, bytes, h->stream));   // pad channels stay zero forever
-            h->dbuf_cs[i] = cs;
-        }
+        h->dbuf.assign(nbufs, nullptr);
+        std::vector<size_t> off;
+        size_t arena_bytes = 0, plain_bytes = 0;
+        plan_memory(h, nb, Hl, Wl, &off, nullptr, &arena_bytes, &plain_bytes);
+        HIPCHK(hipMalloc(&h->arena, std::max<size_t>(arena_bytes, 256)));
+        HIPCHK(hipMemsetAsync(h->arena, 0, arena_bytes, h->stream));       // pad channels (pinned buffers) stay zero forever
+        for (size_t i = 0; i < nbufs; ++i) h->dbuf[i] = (float*)(h->arena + off[i]);
+        h->act_bytes = (long long)arena_bytes; h->act_bytes_noreuse = (long long)plain_bytes;
         int A = 0;
         for (const FileLevel& lv : h->levels) A += (Hl / lv.stride) * (Wl / lv.stride);
         h->A = A; h->Apow2 = 1; while (h->Apow2 < A) h->Apow2 <<= 1;
@@ -1371,12 +1453,33 @@ int mi355_yolo_sync(mi355_yolo* h) {
     return MI355_OK;
 }
 
-int mi355_yolo_plan_info(const mi355_yolo* h, unsigned long long* plan_hash, int* source, int* launches, long long* activation_bytes) {
+int mi355_yolo_plan_info(const mi355_yolo* h, unsigned long long* plan_hash, int* source, int* launches, long long* activation_bytes,
+                         long long* activation_bytes_unshared) {
     if (!h) return fail(MI355_EINVAL, "null argument");
     if (plan_hash) *plan_hash = h->plan_hash;
     if (source) *source = h->plan_source;
     if (launches) *launches = h->plan_launches;
     if (activation_bytes) *activation_bytes = h->act_bytes;
+    if (activation_bytes_unshared) *activation_bytes_unshared = h->act_bytes_noreuse;
+    return MI355_OK;
+}
+
+int mi355_memory_plan(const void* blob, size_t nbytes, int n, int height, int width, int imgsz, int half, int reuse, long long* offsets,
+                      long long* sizes, int cap, int* n_buffers, long long* arena_bytes, long long* unshared_bytes) {
+    if (!blob || n <= 0 || height <= 0 || width <= 0 || cap < 0 || (cap > 0 && (!offsets || !sizes))) return fail(MI355_EINVAL, "bad argument");
+    if (imgsz <= 0) imgsz = 640;
+    if (imgsz % 32) return fail(MI355_EINVAL, "imgsz must be a multiple of 32");
+    mi355_yolo h;
+    h.host_only = true; h.half = half != 0;
+    const int rc = parse_blob(&h, (const uint8_t*)blob, nbytes); if (rc) return rc;
+    h.mem_reuse = reuse;
+    const Geometry g = make_geometry(height, width, imgsz);
+    std::vector<size_t> off, bytes; size_t arena = 0, plain = 0;
+    plan_memory(&h, n, g.Hl, g.Wl, &off, &bytes, &arena, &plain);
+    if (n_buffers) *n_buffers = (int)off.size();
+    for (size_t i = 0; i < off.size() && (int)i < cap; ++i) { offsets[i] = (long long)off[i]; sizes[i] = (long long)bytes[i]; }
+    if (arena_bytes) *arena_bytes = (long long)arena;
+    if (unshared_bytes) *unshared_bytes = (long long)plain;
     return MI355_OK;
 }
 

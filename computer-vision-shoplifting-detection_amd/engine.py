@@ -296,10 +296,11 @@ class YOLO:
     def plan_info(self) -> dict:
         """Launch plans of the shape last run: hash (candidates + choices), where the choices came from, launches per pass and
         the activation footprint in bytes."""
-        hsh, src, nl, ab = C.c_ulonglong(), C.c_int(), C.c_int(), C.c_longlong()
-        _lib.check(_lib.lib().mi355_yolo_plan_info(getattr(self, "_last_handle", self._h), C.byref(hsh), C.byref(src), C.byref(nl), C.byref(ab)))
+        hsh, src, nl, ab, au = C.c_ulonglong(), C.c_int(), C.c_int(), C.c_longlong(), C.c_longlong()
+        _lib.check(_lib.lib().mi355_yolo_plan_info(getattr(self, "_last_handle", self._h), C.byref(hsh), C.byref(src), C.byref(nl), C.byref(ab),
+                                                   C.byref(au)))
         return {"plan_hash": f"{hsh.value:016x}", "plan_source": ("static", "memory", "file", "tuned")[src.value & 3],
-                "launches_per_pass": nl.value, "activation_bytes": ab.value}
+                "launches_per_pass": nl.value, "activation_bytes": ab.value, "activation_bytes_unshared": au.value}
 
     def set_profiling(self, on: bool = True) -> None:
         _lib.check(_lib.lib().mi355_yolo_set_profiling(self._h, int(on)))

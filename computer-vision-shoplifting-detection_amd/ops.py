@@ -130,3 +130,15 @@ def plan_versions(n: int, h: int, w: int, cin: int, cout: int, k: int, stride: i
     _lib.check(_lib.lib().mi355_plan_query(n, h, w, cin, cout, k, stride, src_cs or r4(cin), dst_cs or r4(cout), res_cs, f2_cout,
                                            f2_dst_cs or r4(f2_cout), int(half), out, cap, C.byref(npl)))
     return [out[i] for i in range(min(cap, npl.value))]
+
+
+def memory_plan(blob: bytes, n: int, height: int, width: int, imgsz: int = 640, half: bool = False, reuse: bool = True):
+    """Where the engine would place the activation buffers of weight image ``blob`` for ``n`` frames per pass (host-only query):
+    -> (offsets [n_buffers], sizes [n_buffers], arena_bytes, unshared_bytes)."""
+    cap = 4096
+    off, sz = (C.c_longlong * cap)(), (C.c_longlong * cap)()
+    nb, arena, plain = C.c_int(0), C.c_longlong(0), C.c_longlong(0)
+    _lib.check(_lib.lib().mi355_memory_plan(blob, len(blob), n, height, width, imgsz, int(half), int(reuse), off, sz, cap, C.byref(nb),
+                                            C.byref(arena), C.byref(plain)))
+    k = nb.value
+    return np.array(off[:k], dtype=np.int64), np.array(sz[:k], dtype=np.int64), arena.value, plain.value

@@ -143,9 +143,16 @@ int  mi355_yolo_raw_head(mi355_yolo* h, const uint8_t* bgr_nhwc, int n, int heig
 /* Launch plans of the shape last run: plan_hash identifies the candidate lists AND the choice per conv (two runs with the same
  * hash launch the same kernels with the same grids); source 0 = static guess (autotune off), 1 = this process's memory,
  * 2 = plan file, 3 = timed now; launches = kernel launches of one pass (stem .. last conv; decode and NMS follow);
- * activation_bytes = device memory held by the activation buffers.  Any out pointer may be NULL. */
+ * activation_bytes = device memory held by the activation arena (buffers whose lifetimes cannot overlap under any legal
+ * schedule share bytes), activation_bytes_unshared = what one region per graph tensor would take.  Any out pointer may be NULL. */
 int  mi355_yolo_plan_info(const mi355_yolo* h, unsigned long long* plan_hash, int* source, int* launches,
-                          long long* activation_bytes);
+                          long long* activation_bytes, long long* activation_bytes_unshared);
+/* Host-only: where the activation buffers of a weight image would live for n frames of height x width per pass (byte offsets
+ * into the engine's arena and sizes, per program buffer, in .mi355w buffer order) -- the liveness-based placement the engine
+ * uses, computed without a device.  reuse = 0: one region per buffer.  For the memory planner's unit tests. */
+int  mi355_memory_plan(const void* blob, size_t nbytes, int n, int height, int width, int imgsz, int half, int reuse,
+                       long long* offsets, long long* sizes, int cap, int* n_buffers, long long* arena_bytes,
+                       long long* unshared_bytes);
 /* Per-kernel-kind timing costs two HIP events per launch; off by default (total_ms is always measured). */
 int  mi355_yolo_set_profiling(mi355_yolo* h, int on);
 int  mi355_yolo_last_timing(const mi355_yolo* h, mi355_timing* t);

@@ -76,7 +76,8 @@ def test_bench_self_launch_fails_loudly_when_a_rank_fails():
     """more ranks than GPUs (and no dry-run switch): the ranks without a GPU exit non-zero, the launcher stops the others, prints
     no result line and returns non-zero"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "BENCH_DRYRUN_ONE_GPU")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--batch", "2", "--steps", "1", "--warmup", "0"],
+    # 3 ranks on a 1-GPU box: ranks 1 and 2 find no GPU of their own (kept small: a box admits few processes on its GPU at once)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--batch", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert p.returncode != 0
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
