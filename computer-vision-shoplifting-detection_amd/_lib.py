@@ -74,9 +74,14 @@ SIGNATURES = {
                                         C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, _i32p]),
     "mi355_op_conv2d_fused_f16": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                             C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, _i32p]),
+    "mi355_op_conv2d_group": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i32p, _i32p,
+                                        C.c_void_p, C.c_void_p, C.c_int]),
     "mi355_bench_conv2d": (C.c_int, [C.c_int] * 12 + [_f32p, _i32p, C.c_char_p, C.c_int]),
     "mi355_bench_conv2d_f16": (C.c_int, [C.c_int] * 12 + [_f32p, _i32p, C.c_char_p, C.c_int]),
     "mi355_plan_query": (C.c_int, [C.c_int] * 13 + [_i32p, C.c_int, _i32p]),
+    "mi355_gmc_pyr_lk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                   C.c_double, C.c_void_p, C.c_void_p]),
     "mi355_op_stem": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_int, C.c_int, C.c_void_p]),
     "mi355_letterbox_shape": (C.c_int, [C.c_int, C.c_int, C.c_int, _i32p, _i32p]),

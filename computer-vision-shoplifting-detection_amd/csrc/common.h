@@ -88,15 +88,15 @@ struct ConvLaunch { const void* fn; unsigned grid_x, grid_y; size_t lds; ConvKAr
 // (`kind` = index into a fixed menu of conv_igemm_f32 / conv_splitk_f32 / conv1x1_stream_f32 instances) on its own arguments.
 // In the latency-bound regime (a few frames per pass) a launch costs 5-15 us whatever it computes and leaves most CUs idle; a
 // group costs max(members) instead of sum(members) -- what several streams would buy without their cross-queue event waits.
-constexpr int kGroupMax = 4;
-struct GroupKArgs {
+constexpr int kGroupMax = 3;
+struct GroupHdr {
     int n;
     unsigned base[kGroupMax + 1];      // first block of member m (multiples of 8: the XCD-aware work order stays valid per member)
     int kind[kGroupMax];
     unsigned gx[kGroupMax], gy[kGroupMax];
-    ConvKArgs a[kGroupMax];
 };
-struct GroupLaunch { GroupKArgs k; unsigned grid; size_t lds; int n_members; int op[kGroupMax]; void* dev; };   // dev: device copy of k (owner: the engine)
+struct GroupKArgs { GroupHdr hdr; ConvKArgs a[kGroupMax]; };       // each a[m] travels as a by-value kernel parameter of its own
+struct GroupLaunch { GroupKArgs k; unsigned grid; size_t lds; int n_members; int op[kGroupMax]; };
 // menu index of a planned launch, or -1 when its kernel instance is not part of the group kernel
 int group_kind(const ConvLaunch& l, int ks, int stride);
 const char* plan_group(const std::vector<ConvLaunch>& members, const std::vector<int>& kinds, GroupLaunch* out);

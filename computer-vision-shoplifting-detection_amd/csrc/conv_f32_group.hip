@@ -27,32 +27,11 @@ __device__ __forceinline__ int log2i(int v) { return v == 4 ? 2 : v == 2 ? 1 : 0
     case base + 10: conv_igemm_f32_body<3, st, 2, 2, 2, f2>(a, lds, bid); break;                                             \
     case base + 11: conv_igemm_f32_body<3, st, 2, 2, 4, f2>(a, lds, bid); break;
 
-// The arguments live in device memory and are read through the CONSTANT address space: every field then arrives by scalar
-// loads into SGPRs exactly as a kernel's own argument block does (the kernel bodies pin several derived values to SGPRs).
-__global__ __launch_bounds__(256, 4) void conv_group_f32(const GroupKArgs* gp) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    typedef const __attribute__((address_space(4))) unsigned* CU32;
-    const CU32 gw = (CU32)gp;                            // the argument block as dwords
-    constexpr int OFF_BASE = offsetof(GroupKArgs, base) / 4, OFF_KIND = offsetof(GroupKArgs, kind) / 4, OFF_GX = offsetof(GroupKArgs, gx) / 4,
-                  OFF_GY = offsetof(GroupKArgs, gy) / 4, OFF_A = offsetof(GroupKArgs, a) / 4, A_WORDS = sizeof(ConvKArgs) / 4;
-    static_assert(sizeof(ConvKArgs) % 4 == 0 && offsetof(GroupKArgs, a) % 8 == 0, "argument block layout");
-    // member of this block: block-uniform (scalar compares on blockIdx.x)
-    const int n = (int)gw[0];
-    int m = 0;
-#pragma unroll
-    for (int i = 1; i < kGroupMax; ++i)
-        if (i < n && blockIdx.x >= gw[OFF_BASE + i]) m = i;
-    const unsigned local = blockIdx.x - gw[OFF_BASE + m];
-    const unsigned gx = gw[OFF_GX + m], gy = gw[OFF_GY + m];
-    if (local >= gx * gy) return;                        // padding blocks (member ranges are rounded up to multiples of 8)
-    const int kind = (int)gw[OFF_KIND + m];
-    ConvKArgs a;
-    {
-        unsigned* aw = (unsigned*)&a;
-#pragma unroll
-        for (int i = 0; i < A_WORDS; ++i) aw[i] = gw[OFF_A + m * A_WORDS + i];
-    }
-    const BlockId bid{local % gx, local / gx, gx, gy};
+// One member's work: its kernel instance (`kind`) on its arguments.  Force-inlined once per member SLOT, so that `a` is always a
+// by-value kernel parameter at a static offset of the kernarg segment: every field then arrives by on-demand scalar loads, exactly
+// as in the stand-alone kernels.  (A first version copied the selected member's arguments out of an array: 75 dwords loaded up
+// front, 370 SGPRs spilled to VGPR lanes -- and sporadically wrong accumulator lanes in the LDS-free streaming member.)
+__device__ __forceinline__ void run_member(const ConvKArgs& a, int kind, float* lds, const BlockId& bid) {
     switch (kind) {
         MI355_G_IGEMM_CASES(1, false, 0)
         MI355_G_IGEMM_CASES(1, true, 12)
@@ -76,6 +55,24 @@ __global__ __launch_bounds__(256, 4) void conv_group_f32(const GroupKArgs* gp) {
     }
 }
 
+#ifndef MI355_GROUP_MINWAVES
+#define MI355_GROUP_MINWAVES 4      // the widest menu instance sets every member's register count: 4 waves per SIMD = 128 registers
+#endif
+__global__ __launch_bounds__(256, MI355_GROUP_MINWAVES) void conv_group_f32(GroupHdr hdr, ConvKArgs a0, ConvKArgs a1, ConvKArgs a2) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    static_assert(kGroupMax == 3, "one by-value argument block per member slot");
+    // member of this block: block-uniform (scalar compares on blockIdx.x)
+    const int m = (hdr.n > 2 && blockIdx.x >= hdr.base[2]) ? 2 : (hdr.n > 1 && blockIdx.x >= hdr.base[1]) ? 1 : 0;
+    const unsigned local = blockIdx.x - hdr.base[m];
+    const unsigned gx = hdr.gx[m], gy = hdr.gy[m];
+    if (local >= gx * gy) return;                        // padding blocks (member ranges are rounded up to multiples of 8)
+    const BlockId bid{local % gx, local / gx, gx, gy};
+    const int kind = hdr.kind[m];
+    if (m == 0) run_member(a0, kind, lds, bid);
+    else if (m == 1) run_member(a1, kind, lds, bid);
+    else run_member(a2, kind, lds, bid);
+}
+
 int group_kind(const ConvLaunch& l, int ks, int stride) {
     const bool f2 = l.a.w2 != nullptr;
     auto lg = [](int v) { return v == 4 ? 2 : v == 2 ? 1 : v == 1 ? 0 : -1; };
@@ -89,22 +86,23 @@ int group_kind(const ConvLaunch& l, int ks, int stride) {
 }
 
 const char* plan_group(const std::vector<ConvLaunch>& members, const std::vector<int>& kinds, GroupLaunch* out) {
-    if (members.size() < 2 || members.size() > (size_t)kGroupMax || kinds.size() != members.size()) return "group: 2..4 members";
+    if (members.size() < 2 || members.size() > (size_t)kGroupMax || kinds.size() != members.size()) return "group: 2..3 members";
     GroupLaunch g{};
-    g.n_members = g.k.n = (int)members.size();
+    g.n_members = g.k.hdr.n = (int)members.size();
     unsigned at = 0;
     size_t lds = 0;
     for (size_t m = 0; m < members.size(); ++m) {
         const ConvLaunch& l = members[m];
         if (kinds[m] < 0 || kinds[m] >= G_KINDS || l.threads != 256) return "group: member kernel is not on the menu";
-        g.k.base[m] = at;
-        g.k.kind[m] = kinds[m];
-        g.k.gx[m] = l.grid_x; g.k.gy[m] = l.grid_y;
+        g.k.hdr.base[m] = at;
+        g.k.hdr.kind[m] = kinds[m];
+        g.k.hdr.gx[m] = l.grid_x; g.k.hdr.gy[m] = l.grid_y;
         g.k.a[m] = l.a;
         at += (l.grid_x * l.grid_y + 7u) & ~7u;
         lds = std::max(lds, l.lds);
     }
-    for (size_t m = members.size(); m <= (size_t)kGroupMax; ++m) g.k.base[m] = at;
+    for (size_t m = members.size(); m <= (size_t)kGroupMax; ++m) g.k.hdr.base[m] = at;
+    for (size_t m = members.size(); m < (size_t)kGroupMax; ++m) g.k.a[m] = members[0].a;        // unused slots: any valid block
     if (at >= (1u << 24)) return "group: too many blocks";
     g.grid = at; g.lds = lds;
     *out = g;
@@ -112,8 +110,7 @@ const char* plan_group(const std::vector<ConvLaunch>& members, const std::vector
 }
 
 const char* run_group(const GroupLaunch& g, hipStream_t st) {
-    if (!g.dev) return "group: arguments were not uploaded";
-    hipLaunchKernelGGL(conv_group_f32, dim3(g.grid), dim3(256), g.lds, st, (const GroupKArgs*)g.dev);
+    hipLaunchKernelGGL(conv_group_f32, dim3(g.grid), dim3(256), g.lds, st, g.k.hdr, g.k.a[0], g.k.a[1], g.k.a[2]);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

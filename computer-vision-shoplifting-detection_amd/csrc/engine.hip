@@ -212,7 +212,6 @@ void mi355_yolo::free_shape() {
     if (arena) (void)hipFree(arena);
     arena = nullptr;
     dbuf.clear(); dbuf_cs.clear(); dbuf_es.clear(); plans.clear();
-    for (auto& g : groups) if (g.dev) (void)hipFree(g.dev);
     groups.clear(); steps.clear();
     if (pred) (void)hipFree(pred); if (best) (void)hipFree(best); if (keys) (void)hipFree(keys);
     if (lbox) (void)hipFree(lbox);
@@ -568,7 +567,8 @@ static void plan_memory(mi355_yolo* h, int nb, int Hl, int Wl, std::vector<size_
         const int es = (h->half && !is_head) ? 2 : 4;
         const int cs = round_up((int)h->bufs[i].channels, 16 / es);
         h->dbuf_es[i] = es; h->dbuf_cs[i] = cs;
-        bytes[i] = round_up_sz((size_t)nb * (Hl / h->bufs[i].stride_div) * (Wl / h->bufs[i].stride_div) * cs * es, 256);
+        static const size_t arena_align = getenv("MI355_ARENA_ALIGN") ? (size_t)std::max(256, atoi(getenv("MI355_ARENA_ALIGN"))) : 256;
+        bytes[i] = round_up_sz((size_t)nb * (Hl / h->bufs[i].stride_div) * (Wl / h->bufs[i].stride_div) * cs * es, arena_align);
         // bytes of its own, forever: head outputs (the decode kernel reads them after the last op) and buffers with pad
         // channels (cs > channels: zeroed once here, read -- times zero weights -- by the convs' padded k-blocks, never
         // written: another tensor's bits there could be NaN patterns)
@@ -588,6 +588,9 @@ static void plan_memory(mi355_yolo* h, int nb, int Hl, int Wl, std::vector<size_
         if (o.res_buf >= 0) use(o.res_buf);
         use(o.dst_buf); writers[o.dst_buf].push_back(i);
         if (h->fuse_up[i] >= 0) use(h->ops[h->fuse_up[i]].src_buf);
+        // a pointwise conv that may run INSIDE this op's launch (Conv3x3 -> Conv1x1 fused): its output is then written while
+        // this op still reads its own inputs, so this op counts as a writer (and user) of that output buffer as well
+        if (h->fuse2[i] >= 0) { const int d2 = h->ops[h->fuse2[i]].dst_buf; use(d2); writers[d2].push_back(i); }
     }
     auto is_anc = [&](int a, int of) { return (h->anc[of][a >> 6] >> (a & 63)) & 1ull; };
     auto may_share = [&](size_t a, size_t b) {          // may b (written later) take a's bytes?
@@ -831,7 +834,6 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
         }
     }
     // ---- grouped launches of the single-stream regime: list-schedule the launched ops into steps, then decide per step ----
-    for (auto& g : h->groups) if (g.dev) (void)hipFree(g.dev);
     h->groups.clear(); h->steps.clear();
     h->group_sel.assign(n_ops, -1);
     const bool stepwise = h->use_groups && !h->half && nb <= h->group_max_batch && nb < h->streams_min_batch;
@@ -906,8 +908,6 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                 for (const Member& m : mem) { ls.push_back(m.l); kinds.push_back(m.kind); t_sum += m.t_ind; }
                 GroupLaunch g{};
                 if (plan_group(ls, kinds, &g) != nullptr) continue;
-                HIPCHK(hipMalloc(&g.dev, sizeof(GroupKArgs)));
-                HIPCHK(hipMemcpy(g.dev, &g.k, sizeof(GroupKArgs), hipMemcpyHostToDevice));
                 float t_grp = 1e30f;
                 for (int rep = 0; rep < 4; ++rep) {
                     HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -918,13 +918,17 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                     HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
                     if (rep > 0) t_grp = std::min(t_grp, t / 8.0f);
                 }
-                (void)hipFree(g.dev);
+                static int dbg_seq = 0;
+                const char* only = getenv("MI355_GROUP_ONLY");        // debugging: accept only the n-th candidate group
+                const bool dbg_ok = !only || atoi(only) == dbg_seq;
+                ++dbg_seq;
                 if (tune_log) {
                     fprintf(stderr, "[tune] group of %zu:", mem.size());
-                    for (const Member& m : mem) fprintf(stderr, " %s(%.1f us)", h->convs[h->ops[m.op].conv].name, m.t_ind * 1e3);
+                    for (const Member& m : mem) fprintf(stderr, " %s(%.1f us; kind %d v%d PT%d CT%d WP%d G%d grid %ux%u lds %zu%s%s)", h->convs[h->ops[m.op].conv].name, m.t_ind * 1e3,
+                                                        m.kind, m.l.version, m.l.PT, m.l.CT, m.l.WP, m.l.a.cgroups, m.l.grid_x, m.l.grid_y, m.l.lds, m.l.a.w2 ? " +1x1" : "", m.l.a.res ? " +res" : "");
                     fprintf(stderr, " : grouped %.1f us vs separate %.1f us -> %s\n", t_grp * 1e3, t_sum * 1e3, t_grp < 0.97f * t_sum ? "grouped" : "separate");
                 }
-                if (t_grp < 0.97f * t_sum)
+                if (t_grp < 0.97f * t_sum && h->use_groups != 2 && dbg_ok)         // MI355_GROUPS=2: step order without grouped launches (debugging)
                     for (const Member& m : mem) gsel[m.op] = m.sel;
             }
             have_groups = true;
@@ -946,12 +950,21 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
             GroupLaunch g{};
             if (plan_group(ls, kinds, &g) != nullptr) continue;
             for (size_t m = 0; m < members.size(); ++m) { g.op[m] = members[m]; h->group_sel[members[m]] = gsel[members[m]]; }
-            HIPCHK(hipMalloc(&g.dev, sizeof(GroupKArgs)));
-            HIPCHK(hipMemcpy(g.dev, &g.k, sizeof(GroupKArgs), hipMemcpyHostToDevice));
             st.singles = singles; st.group = (int)h->groups.size();
             h->groups.push_back(g);
         }
     }
+    if (getenv("MI355_SCHED_LOG"))
+        for (size_t k = 0; k < h->steps.size(); ++k) {
+            fprintf(stderr, "[step] %zu: singles", k);
+            for (int i : h->steps[k].singles) fprintf(stderr, " %d:%s", i, h->ops[i].type == OP_CONV || h->ops[i].type == OP_STEM ? h->convs[h->ops[i].conv].name : h->ops[i].type == OP_UPSAMPLE ? "upsample" : "sppf_pools");
+            if (h->steps[k].group >= 0) {
+                fprintf(stderr, " | group");
+                const GroupLaunch& g = h->groups[h->steps[k].group];
+                for (int m = 0; m < g.n_members; ++m) fprintf(stderr, " %d:%s", g.op[m], h->convs[h->ops[g.op[m]].conv].name);
+            }
+            fprintf(stderr, "\n");
+        }
     if (have) {
         std::vector<int> both(chosen);
         both.insert(both.end(), gsel.begin(), gsel.end());
@@ -1714,6 +1727,71 @@ static int op_conv2d_fused_impl(int device_id, const float* x, int n, int h, int
         halfs_to_floats(hb.data(), yout.data(), hb.size());
     }
     for (size_t p = 0; p < npo; ++p) std::memcpy(y + p * c2, &yout[p * cs_out], (size_t)c2 * 4);
+    return MI355_OK;
+}
+
+// Two independent convs (same input tensor, different weights) run as ONE grouped launch (conv_f32_group.hip) with candidate
+// plans plan_a / plan_b (indices into each conv's candidate list, skipping plans whose kernel is not on the group kernel's
+// menu: *n_menu_a / *n_menu_b return how many are): the parity hook of the grouped launches -- must equal mi355_op_conv2d of each.
+int mi355_op_conv2d_group(int device_id, const float* x, int n, int h, int w, int cin, const float* wa, const float* ba, int cout_a, int k_a,
+                          int stride_a, const float* wb, const float* bb, int cout_b, int k_b, int stride_b, float* ya, float* yb, int plan_a,
+                          int plan_b, int* n_menu_a, int* n_menu_b, const float* w2a, const float* b2a, int cout2_a) {
+    if (!x || !wa || !ba || !wb || !bb || !ya || !yb || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout_a <= 0 || cout_b <= 0) return fail(MI355_EINVAL, "bad argument");
+    if (cout2_a > 0 && (!w2a || !b2a || k_a != 3)) return fail(MI355_EINVAL, "the fused pointwise stage needs weights and a 3x3 first conv");
+    HIPCHK(hipSetDevice(device_id));
+    const int cs_in = round_up(cin, 4);
+    const size_t npi = (size_t)n * h * w;
+    std::vector<float> xin(npi * cs_in, 0.f);
+    for (size_t p = 0; p < npi; ++p) std::memcpy(&xin[p * cs_in], x + p * cin, (size_t)cin * 4);
+    DevMem dm; float *d_x, *d_z;
+    HIPCHK(dm.alloc(&d_z, 256)); HIPCHK(hipMemset(d_z, 0, 256));
+    HIPCHK(dm.alloc(&d_x, xin.size() * 4)); HIPCHK(hipMemcpy(d_x, xin.data(), xin.size() * 4, hipMemcpyHostToDevice));
+    struct One { const float* w; const float* b; int cout, k, stride; float* y; int cout2; float* d_y; int cs_out; size_t npo; std::vector<ConvLaunch> menu; std::vector<int> kinds; };
+    One c[2] = {{wa, ba, cout_a, k_a, stride_a, ya, cout2_a > 0 ? cout2_a : 0}, {wb, bb, cout_b, k_b, stride_b, yb, 0}};
+    for (One& o : c) {
+        if (!((o.k == 1 && o.stride == 1) || (o.k == 3 && (o.stride == 1 || o.stride == 2))) || (h % o.stride) || (w % o.stride)) return fail(MI355_EINVAL, "k/stride not supported");
+        const int c_final = o.cout2 ? o.cout2 : o.cout;                 // channels of the tensor that is written
+        o.cs_out = round_up(c_final, 4); o.npo = (size_t)n * (h / o.stride) * (w / o.stride);
+        float *d_w, *d_b;
+        std::vector<float> pk(packed_weight_floats(o.cout, cin, o.k)), bp(round_up(o.cout, 16), 0.f);
+        pack_conv_weights(o.w, o.cout, cin, o.k, pk.data());
+        std::memcpy(bp.data(), o.b, (size_t)o.cout * 4);
+        HIPCHK(dm.alloc(&d_w, pk.size() * 4)); HIPCHK(hipMemcpy(d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(dm.alloc(&d_b, bp.size() * 4)); HIPCHK(hipMemcpy(d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(dm.alloc(&o.d_y, o.npo * o.cs_out * 4)); HIPCHK(hipMemset(o.d_y, 0, o.npo * o.cs_out * 4));
+        ConvArgs a{};
+        a.src = d_x; a.src_cs = cs_in; a.dst = o.d_y; a.dst_cs = o.cs_out; a.wpk = d_w; a.bias = d_b; a.zeros = d_z;
+        a.B = n; a.Hin = h; a.Win = w; a.Hout = h / o.stride; a.Wout = w / o.stride; a.Cin = cin; a.Cout = o.cout; a.k = o.k; a.stride = o.stride;
+        a.pad = o.k / 2; a.act = 1;
+        if (o.cout2) {                       // Conv3x3 -> Conv1x1 fused: the 3x3's own output goes nowhere, the 1x1 writes d_y
+            float *d_mid, *d_w2, *d_b2;
+            HIPCHK(dm.alloc(&d_mid, o.npo * round_up(o.cout, 4) * 4));
+            std::vector<float> pk2(packed_weight_floats(o.cout2, o.cout, 1)), bp2(round_up(o.cout2, 16), 0.f);
+            pack_conv_weights(w2a, o.cout2, o.cout, 1, pk2.data());
+            std::memcpy(bp2.data(), b2a, (size_t)o.cout2 * 4);
+            HIPCHK(dm.alloc(&d_w2, pk2.size() * 4)); HIPCHK(hipMemcpy(d_w2, pk2.data(), pk2.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(dm.alloc(&d_b2, bp2.size() * 4)); HIPCHK(hipMemcpy(d_b2, bp2.data(), bp2.size() * 4, hipMemcpyHostToDevice));
+            a.dst = d_mid; a.dst_cs = round_up(o.cout, 4);
+            a.f2_wpk = d_w2; a.f2_bias = d_b2; a.f2_dst = o.d_y; a.f2_dst_cs = o.cs_out; a.f2_cout = o.cout2; a.f2_act = 0;
+        }
+        std::vector<ConvLaunch> cands;
+        KCHK(plan_conv_candidates(a, &cands));
+        for (const ConvLaunch& l : cands) { const int kd = group_kind(l, o.k, o.stride); if (kd >= 0) { o.menu.push_back(l); o.kinds.push_back(kd); } }
+    }
+    if (n_menu_a) *n_menu_a = (int)c[0].menu.size();
+    if (n_menu_b) *n_menu_b = (int)c[1].menu.size();
+    if (c[0].menu.empty() || c[1].menu.empty()) return fail(MI355_EINVAL, "no candidate plan of one conv is on the group kernel's menu");
+    const size_t ia = (size_t)(plan_a < 0 ? 0 : plan_a) % c[0].menu.size(), ib = (size_t)(plan_b < 0 ? 0 : plan_b) % c[1].menu.size();
+    GroupLaunch g{};
+    KCHK(plan_group({c[0].menu[ia], c[1].menu[ib]}, {c[0].kinds[ia], c[1].kinds[ib]}, &g));
+    KCHK(run_group(g, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    for (One& o : c) {
+        std::vector<float> yo(o.npo * o.cs_out);
+        HIPCHK(hipMemcpy(yo.data(), o.d_y, yo.size() * 4, hipMemcpyDeviceToHost));
+        const int c_final = o.cout2 ? o.cout2 : o.cout;
+        for (size_t p = 0; p < o.npo; ++p) std::memcpy(o.y + p * c_final, &yo[p * o.cs_out], (size_t)c_final * 4);
+    }
     return MI355_OK;
 }
 

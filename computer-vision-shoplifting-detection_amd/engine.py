@@ -268,7 +268,8 @@ class YOLO:
             # trackers/track.py:on_predict_postprocess_end: the tracker steps on EVERY frame (an empty frame still advances
             # frame_id, ages lost tracks against track_buffer and runs the Kalman predict); only the rewrite of the
             # result is skipped when no track comes back
-            tracks = self._tracker.update(res.boxes.data.numpy())
+            frame = originals[i] if originals is not None else batch[i].cpu().numpy()
+            tracks = self._tracker.update(res.boxes.data.numpy(), frame)   # trackers/track.py: tracker.update(det, im0)
             if len(tracks):
                 idx = tracks[:, -1].astype(int)
                 res = res[idx]

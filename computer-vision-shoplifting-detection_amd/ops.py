@@ -142,3 +142,23 @@ def memory_plan(blob: bytes, n: int, height: int, width: int, imgsz: int = 640, 
                                             C.byref(arena), C.byref(plain)))
     k = nb.value
     return np.array(off[:k], dtype=np.int64), np.array(sz[:k], dtype=np.int64), arena.value, plain.value
+
+
+def conv2d_group(x_nhwc: np.ndarray, wa: np.ndarray, ba: np.ndarray, wb: np.ndarray, bb: np.ndarray, stride_a: int = 1, stride_b: int = 1,
+                 plan_a: int = 0, plan_b: int = 0, device: int = 0, w2a: Optional[np.ndarray] = None, b2a: Optional[np.ndarray] = None):
+    """Two independent convs of one input as ONE grouped launch (conv_f32_group.hip): -> (ya, yb, n_menu_a, n_menu_b).
+    ``w2a`` / ``b2a``: a pointwise conv fused behind conv a (3x3), as in :func:`conv2d_fused`; ya is then its output."""
+    x, wa, ba, wb, bb = _f32(x_nhwc), _f32(wa), _f32(ba), _f32(wb), _f32(bb)
+    n, h, wd, cin = x.shape
+    c2 = 0
+    if w2a is not None:
+        w2a, b2a = _f32(w2a), _f32(b2a)
+        c2 = w2a.shape[0]
+    ya = np.empty((n, h // stride_a, wd // stride_a, c2 or wa.shape[0]), dtype=np.float32)
+    yb = np.empty((n, h // stride_b, wd // stride_b, wb.shape[0]), dtype=np.float32)
+    na, nb = C.c_int(0), C.c_int(0)
+    _lib.check(_lib.lib().mi355_op_conv2d_group(device, x.ctypes.data, n, h, wd, cin, wa.ctypes.data, ba.ctypes.data, wa.shape[0], wa.shape[2],
+                                                stride_a, wb.ctypes.data, bb.ctypes.data, wb.shape[0], wb.shape[2], stride_b, ya.ctypes.data,
+                                                yb.ctypes.data, int(plan_a), int(plan_b), C.byref(na), C.byref(nb),
+                                                w2a.ctypes.data if c2 else None, b2a.ctypes.data if c2 else None, c2))
+    return ya, yb, na.value, nb.value

@@ -54,8 +54,8 @@ def video_to_poselift(model, frames: Iterable[np.ndarray], out_path: Optional[st
         nonlocal n
         if not buf:
             return
-        for res in model.predict(np.stack(buf), conf=min(conf, 0.1), **predict_kw):
-            rows = tracker.update(res.boxes.data.numpy())      # every frame, empty ones too (frame_id / lost-track ageing)
+        for frame, res in zip(buf, model.predict(np.stack(buf), conf=min(conf, 0.1), **predict_kw)):
+            rows = tracker.update(res.boxes.data.numpy(), frame)      # every frame, empty ones too (frame_id / lost-track ageing)
             if len(rows):
                 rows = clip_boxes(rows.copy(), res.orig_shape)  # Results.update clips the track boxes to the frame
                 idx = rows[:, -1].astype(int)

@@ -52,8 +52,8 @@ def process_clip(model, cap, batch: int = 64, conf: float = 0.1, classes=(0,), *
     def flush():
         if not buf:
             return
-        for n, res in zip(nums, model.predict(np.stack(buf), conf=conf, classes=list(classes), **predict_kw)):
-            tracks = tracker.update(res.boxes.data.numpy())    # every frame, empty ones too (frame_id / lost-track ageing)
+        for n, frame, res in zip(nums, buf, model.predict(np.stack(buf), conf=conf, classes=list(classes), **predict_kw)):
+            tracks = tracker.update(res.boxes.data.numpy(), frame)    # every frame, empty ones too (frame_id / lost-track ageing)
             if len(tracks):                                    # `if not boxes.is_track: return` otherwise (model.py:45)
                 b = Boxes(clip_boxes(torch.as_tensor(tracks[:, :-1], dtype=torch.float32), res.orig_shape), res.orig_shape)
                 for box in b:

@@ -8,10 +8,13 @@ tracks born after the first frame, and output rows ``[x1,y1,x2,y2,id,score,cls,i
 
 This module implements that published algorithm from its definitions, organised around a table of plain records and a
 structure-exploiting Kalman filter (the transition is ``x += v``, the measurement is the first four state components, so
-no motion / projection matrices are ever formed).  Not implemented: global motion compensation
-(``gmc_method: sparseOptFlow`` needs OpenCV's optical flow -- identity here, correct for the fixed CCTV cameras of
-UCF-Crime) and ReID (``with_reid: False`` is the default).  Assignment is SciPy's Hungarian solver, as in Ultralytics'
-``linear_assignment(use_lap=False)`` path.  Tracking is sequential per video and stays on the host.
+no motion / projection matrices are ever formed).  Global motion compensation (``gmc_method: sparseOptFlow``, the
+botsort.yaml default) is ``gmc.py``: when ``update`` is handed the frame, the background's partial-affine motion since the
+previous frame is estimated (Shi-Tomasi corners, pyramidal Lucas-Kanade, RANSAC) and applied to the predicted Kalman
+state of every pooled and every unconfirmed track before association, as ``BOTSORT`` does (``STrack.multi_gmc``);
+``gmc_method=None`` keeps the identity.  Not implemented: ReID (``with_reid: False`` is the default).  Assignment is SciPy's
+Hungarian solver, as in Ultralytics' ``linear_assignment(use_lap=False)`` path.  Tracking is sequential per video and stays
+on the host.
 
 Behaviour is pinned by hand-derived known answers (``tests/test_tracker_known_answers.py``).  PARITY UNPINNED against a
 real Ultralytics run (no ultralytics / lap / cv2 here).
@@ -145,7 +148,9 @@ class BYTETracker:
     """``update(det [N,6] = x1,y1,x2,y2,conf,cls) -> [M,8] = x1,y1,x2,y2,id,score,cls,idx`` (idx = row of ``det``), one call
     per frame, EVERY frame (an empty frame still ages the lost tracks)."""
 
-    def __init__(self, frame_rate: int = 30):
+    def __init__(self, frame_rate: int = 30, gmc_method: Optional[str] = "sparseOptFlow"):
+        from .gmc import GMC
+        self.gmc = GMC(gmc_method)             # BOTSORT.__init__: GMC(method=args.gmc_method); None = identity
         self.frame_id = 0
         self.max_time_lost = int(frame_rate / 30.0 * TRACK_BUFFER)
         self._live: List[Track] = []          # tracked (confirmed or awaiting confirmation), in report order
@@ -178,7 +183,9 @@ class BYTETracker:
             cost = 1 - (1 - cost) * np.array([d.score for d in dets])[None, :]
         return cost
 
-    def update(self, det: np.ndarray) -> np.ndarray:
+    def update(self, det: np.ndarray, img: Optional[np.ndarray] = None) -> np.ndarray:
+        """``img``: the frame the detections come from (BGR uint8, as ``tracker.update(det, im0)`` receives it in
+        trackers/track.py); without it no motion compensation takes place (byte_tracker.py: ``if ... img is not None``)."""
         self.frame_id += 1
         frame = self.frame_id
         det = np.asarray(det, dtype=np.float32).reshape(-1, 6)
@@ -195,6 +202,16 @@ class BYTETracker:
             if t.state != TRACKED:
                 m[6] = m[7] = 0.0
             t.mean, t.cov = KalmanFilterXYWH.predict(m, t.cov)
+        if img is not None and self.gmc.method is not None:
+            # camera motion since the previous frame, applied to the predicted states (pool) and the unconfirmed tracks
+            from .gmc import warp_kalman
+            try:
+                warp = self.gmc.apply(img)
+            except Exception:                                   # byte_tracker.py bypasses errors of the gmc module the same way
+                warp = np.eye(2, 3)
+            if not np.array_equal(warp, np.eye(2, 3)):
+                for t in pool + tentative:
+                    t.mean, t.cov = warp_kalman(t.mean, t.cov, warp)
 
         touched: List[Track] = []        # matched this frame and previously tracked ("activated")
         revived: List[Track] = []        # matched this frame and previously lost ("refound")

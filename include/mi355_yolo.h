@@ -186,6 +186,16 @@ int  mi355_op_conv2d_fused(int device_id, const float* x, int n, int h, int w, i
 int  mi355_op_conv2d_fused_f16(int device_id, const float* x, int n, int h, int w, int cin, const float* w1_oihw, const float* b1,
                                int c1, int stride, const float* w2_oihw, const float* b2, int c2, int silu2, float* y, int out_f32,
                                int plan_index, int* n_plans);
+/* Two independent convs of one input x[n][h][w][cin] (weights wa / wb, SiLU, no residual) as ONE grouped launch -- the way the
+ * engine runs independent convs of one step of the op DAG in the latency-bound regime (the head branches beside the neck).
+ * plan_a / plan_b pick among each conv's candidate plans whose kernel instance is on the group kernel's menu (their counts come
+ * back through n_menu_a / n_menu_b); ya / yb must equal mi355_op_conv2d of each conv alone, bit for bit, for every pair.
+ * cout2_a > 0: conv a is a 3x3 conv with a pointwise conv w2a[cout2_a][cout_a][1][1] / b2a (no activation) fused behind it, as in
+ * mi355_op_conv2d_fused, and ya holds that pointwise conv's output [n][h/stride_a][w/stride_a][cout2_a]. */
+int  mi355_op_conv2d_group(int device_id, const float* x, int n, int h, int w, int cin, const float* wa, const float* ba,
+                           int cout_a, int k_a, int stride_a, const float* wb, const float* bb, int cout_b, int k_b,
+                           int stride_b, float* ya, float* yb, int plan_a, int plan_b, int* n_menu_a, int* n_menu_b,
+                           const float* w2a, const float* b2a, int cout2_a);
 /* Device-resident timing of one conv launch plan on random data (diagnostics / tuning): average milliseconds over
  * `iters` back-to-back launches of candidate plan `plan_index`; plan_desc (optional) receives a description. */
 int  mi355_bench_conv2d(int device_id, int n, int h, int w, int cin, int cout, int k, int stride, int silu, int residual,
@@ -199,6 +209,13 @@ int  mi355_bench_conv2d_f16(int device_id, int n, int h, int w, int cin, int cou
  * (f2_cout > 0).  res_cs = 0: no residual.  For the planner's unit tests (address-range guards). */
 int  mi355_plan_query(int n, int h, int w, int cin, int cout, int k, int stride, int src_cs, int dst_cs, int res_cs,
                       int f2_cout, int f2_dst_cs, int half, int* versions, int cap, int* n_plans);
+/* HOST computation (no GPU): pyramidal Lucas-Kanade optical flow of n points between two gray uint8 frames [height][width] --
+ * the cv2.calcOpticalFlowPyrLK step of BoT-SORT's global motion compensation (ultralytics/trackers/utils/gmc.py, reached
+ * from /root/reference/model.py:38).  win x win windows (odd), max_level + 1 pyramid levels, at most max_iters iterations or
+ * |step| <= eps, points whose window's minimum eigenvalue is below min_eig or which leave the frame get status 0.
+ * pts / next_pts: [n][2] (x, y).  Returns 0, or -1 on a bad argument. */
+int  mi355_gmc_pyr_lk(const uint8_t* prev, const uint8_t* cur, int height, int width, const float* pts, int n, int win,
+                      int max_level, int max_iters, double eps, double min_eig, float* next_pts, uint8_t* status);
 /* The u8 stem: letterboxed BGR frames -> (x/255, RGB) -> conv k x k stride s (pad k/2, or 2 for k=6) + bias + SiLU. */
 int  mi355_op_stem(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias,
                    int cout, int k, int stride, float* y);

@@ -1,0 +1,216 @@
+"""Known-answer tests of BoT-SORT's global motion compensation (cvsd_amd/gmc.py; ``gmc_method: sparseOptFlow``, the
+Ultralytics default behind ``/root/reference/model.py:38``).  OpenCV is not available, so every stage is pinned against
+constructions whose answer is known: hand-computed luma values, corners of drawn squares, analytically shifted / rotated
+images, point sets with planted outliers -- and, end to end, a panning camera over static people."""
+import numpy as np
+import pytest
+
+from cvsd_amd import gmc
+from cvsd_amd.tracker import BYTETracker, KalmanFilterXYWH
+
+
+def _texture(h, w, seed=0, smooth=2):
+    """A band-limited random texture (sum of random sinusoids) as a FUNCTION of continuous coordinates."""
+    rng = np.random.default_rng(seed)
+    k = rng.uniform(-0.45, 0.45, size=(40, 2))
+    ph = rng.uniform(0, 2 * np.pi, size=40)
+    amp = rng.uniform(0.5, 1.0, size=40)
+
+    def f(x, y):
+        v = sum(a * np.sin(kx * x + ky * y + p) for a, (kx, ky), p in zip(amp, k, ph))
+        return np.clip(127.5 + v * 18.0, 0, 255)
+    return f
+
+
+def _render(f, h, w, H=None):
+    """image whose pixel (x, y) shows the texture at the PRE-image of (x, y) under the 2x3 transform H (background moved by H)"""
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    if H is not None:
+        A = np.vstack([H, [0, 0, 1]])
+        Ai = np.linalg.inv(A)
+        xs, ys = Ai[0, 0] * xs + Ai[0, 1] * ys + Ai[0, 2], Ai[1, 0] * xs + Ai[1, 1] * ys + Ai[1, 2]
+    return np.rint(f(xs, ys)).astype(np.uint8)
+
+
+def test_bgr_to_gray_is_opencvs_fixed_point_luma():
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 100], [255, 255, 255]]], dtype=np.uint8)    # B, G, R
+    # (1868 B + 9617 G + 4899 R + 8192) >> 14
+    assert gmc.bgr_to_gray(px).tolist() == [[29, 150, 76, (1868 * 10 + 9617 * 200 + 4899 * 100 + 8192) >> 14, 255]]
+
+
+def test_half_size_linear_resize_is_the_2x2_block_mean():
+    rng = np.random.default_rng(1)
+    g = rng.integers(0, 256, size=(12, 16), dtype=np.uint8)
+    want = (g.reshape(6, 2, 8, 2).astype(np.int64).sum((1, 3)) + 2) >> 2
+    np.testing.assert_array_equal(gmc.resize_linear(g, 8, 6), want)
+
+
+def test_shi_tomasi_finds_the_corners_of_drawn_squares_strongest_first():
+    img = np.full((60, 80), 20, np.uint8)
+    img[10:30, 15:40] = 220          # bright rectangle: corners near (15,10) (39,10) (15,29) (39,29)
+    img[40:52, 50:70] = 120          # a weaker one
+    pts = gmc.good_features_to_track(img)
+    assert 8 <= len(pts) <= 64
+    strong = {(15, 10), (39, 10), (15, 29), (39, 29)}
+    for x, y in pts[:4]:             # the four strongest are the bright rectangle's corners (within the 3x3 block)
+        assert min(abs(x - cx) + abs(y - cy) for cx, cy in strong) <= 2
+    found = [min(np.abs(pts - np.array(c)).sum(1)) for c in [(50, 40), (69, 40), (50, 51), (69, 51)]]
+    assert max(found) <= 2           # the weaker rectangle's corners pass the 1 % quality level too
+    assert (pts[:, 0] >= 1).all() and (pts[:, 0] <= 78).all()
+    assert len(gmc.good_features_to_track(np.full((40, 40), 7, np.uint8))) == 0      # flat image: no corner
+
+
+def _smooth_noise(h, w, seed, sigma=2.0):
+    """non-periodic texture: white noise blurred by a separable Gaussian, stretched to 8 bits"""
+    rng = np.random.default_rng(seed)
+    a = rng.normal(size=(h, w))
+    r = int(3 * sigma)
+    k = np.exp(-0.5 * (np.arange(-r, r + 1) / sigma) ** 2)
+    k /= k.sum()
+    a = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 1, a)
+    a = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 0, a)
+    a = (a - a.min()) / (a.max() - a.min())
+    return np.rint(a * 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("shift", [(3.0, -2.0), (1.3, 0.7), (-6.5, 4.25)])
+def test_pyramidal_lk_recovers_a_known_subpixel_translation(shift):
+    """an analytic texture sampled at shifted coordinates: the true displacement is known to any precision"""
+    f = _texture(120, 160, seed=3)
+    prev = _render(f, 120, 160)
+    cur = _render(f, 120, 160, np.array([[1, 0, shift[0]], [0, 1, shift[1]]], float))
+    pts = gmc.good_features_to_track(prev)
+    pts = pts[(pts[:, 0] > 20) & (pts[:, 0] < 140) & (pts[:, 1] > 20) & (pts[:, 1] < 100)][:200]
+    nxt, ok = gmc.calc_optical_flow_pyr_lk(prev, cur, pts)
+    assert ok.mean() > 0.9
+    err = np.abs((nxt - pts)[ok] - np.array(shift))
+    assert np.median(err) < 0.05 and np.quantile(err, 0.9) < 0.1
+
+
+@pytest.mark.parametrize("shift", [(11, 9), (-17, 6), (24, -13)])
+def test_pyramidal_lk_follows_large_integer_shifts_through_the_pyramid(shift):
+    """two crops of one non-periodic image: displacements far beyond a 21-pixel window's reach at full resolution are found
+    on the coarse levels (4 levels: the coarsest sees an eighth of the shift)"""
+    # fine + coarse detail: the coarse levels of the pyramid need structure that survives three 2x reductions
+    big = ((_smooth_noise(300, 400, seed=7, sigma=2.0).astype(np.int32) + _smooth_noise(300, 400, seed=8, sigma=8.0)) // 2).astype(np.uint8)
+    y0, x0 = 60, 80
+    prev = big[y0:y0 + 180, x0:x0 + 240]
+    cur = big[y0 - shift[1]:y0 - shift[1] + 180, x0 - shift[0]:x0 - shift[0] + 240]        # content moves by +shift
+    pts = gmc.good_features_to_track(prev)
+    pts = pts[(pts[:, 0] > 40) & (pts[:, 0] < 200) & (pts[:, 1] > 40) & (pts[:, 1] < 140)][:150]
+    nxt, ok = gmc.calc_optical_flow_pyr_lk(prev, cur, pts)
+    assert ok.mean() > 0.8              # windows on weak structure fail the minimum-eigenvalue test and are dropped
+    err = np.abs((nxt - pts)[ok] - np.array(shift, float))
+    assert np.median(err) < 0.02 and np.quantile(err, 0.8) < 0.1
+
+
+def test_partial_affine_ransac_ignores_outliers_and_refits_on_inliers():
+    rng = np.random.default_rng(5)
+    src = rng.uniform(0, 300, size=(120, 2))
+    ang, sc, t = np.deg2rad(4.0), 1.03, np.array([7.5, -3.25])
+    R = sc * np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+    dst = src @ R.T + t
+    dst[:30] += rng.uniform(20, 60, size=(30, 2))            # a quarter of the matches are wrong (moving people)
+    H, inl = gmc.estimate_affine_partial_2d(src, dst)
+    np.testing.assert_allclose(H, np.hstack([R, t[:, None]]), atol=1e-9)
+    assert inl[30:].all() and not inl[:30].any()
+    noisy = dst + rng.normal(0, 0.2, size=dst.shape)
+    H2, _ = gmc.estimate_affine_partial_2d(src, noisy)
+    np.testing.assert_allclose(H2, np.hstack([R, t[:, None]]), atol=0.05)
+    assert gmc.estimate_affine_partial_2d(src[:1], dst[:1])[0] is None
+
+
+@pytest.mark.parametrize("H", [
+    np.array([[1, 0, 8.0], [0, 1, -6.0]]),                                                   # pan
+    np.array([[np.cos(0.02), -np.sin(0.02), 3.0], [np.sin(0.02), np.cos(0.02), 1.5]]),       # pan + 1.1 degree roll
+    np.array([[1.02, 0, -2.0], [0, 1.02, 4.0]]),                                             # zoom
+])
+def test_gmc_recovers_the_background_transform_within_a_tenth_of_a_pixel(H):
+    """frame pair: the texture moved by H (full-resolution pixels); GMC works at half resolution and scales the translation
+    back, as Ultralytics' GMC does (downscale 2).  Error measured as the displacement error over the frame's corners."""
+    h, w = 240, 320
+    f = _texture(h, w, seed=11)
+    g0 = _render(f, h, w)
+    g1 = _render(f, h, w, H)
+    bgr = lambda g: np.stack([g, g, g], -1)
+    m = gmc.GMC()
+    np.testing.assert_array_equal(m.apply(bgr(g0)), np.eye(2, 3))          # first frame: identity
+    got = m.apply(bgr(g1))
+    corners = np.array([[0, 0], [w, 0], [0, h], [w, h], [w / 2, h / 2]], float)
+    # the estimate lives on the half-size grid: pixel centres map as x_half = (x_full + 0.5) / 2 - 0.5, which leaves a pure
+    # translation unchanged after the x2 rescale and a rotation / zoom about a slightly shifted origin -- compare displacements
+    want = corners @ H[:, :2].T + H[:, 2]
+    have = corners @ got[:, :2].T + got[:, 2]
+    # Ultralytics rescales only the translation (H[0,2], H[1,2] *= downscale); the linear part is resolution-independent
+    pure_translation = np.array_equal(H[:, :2], np.eye(2))
+    # a 21x21 Lucas-Kanade window models translation only: under roll / zoom its estimate carries a small bias, which shows at
+    # the frame's far corners (a 7e-4 error of the linear part is 0.2 px at 320 px); a pan is recovered to well under 0.1 px
+    assert np.abs(have - want).max() < (0.1 if pure_translation else 0.3), (got, H)
+    np.testing.assert_allclose(got[:, :2], H[:, :2], atol=1e-3)
+    np.testing.assert_allclose(got[:, 2], H[:, 2], atol=0.1 if pure_translation else 0.25)
+
+
+def test_warp_of_the_kalman_state_is_strack_multi_gmc():
+    mean = np.array([100.0, 50.0, 20.0, 40.0, 1.0, -2.0, 0.5, 0.25])
+    cov = np.diag(np.arange(1.0, 9.0))
+    H = np.array([[0.0, -1.0, 5.0], [1.0, 0.0, 7.0]])        # quarter turn + translation
+    m, c = gmc.warp_kalman(mean, cov, H)
+    np.testing.assert_allclose(m, [-50 + 5, 100 + 7, -40, 20, 2, 1, -0.25, 0.5])
+    np.testing.assert_allclose(np.diag(c), [2, 1, 4, 3, 6, 5, 8, 7])      # each (x, y) pair's variances swap under the quarter turn
+    m2, c2 = gmc.warp_kalman(mean, cov, np.eye(2, 3))
+    np.testing.assert_array_equal(m2, mean)
+    np.testing.assert_array_equal(c2, cov)
+
+
+def test_ids_survive_a_panning_camera_with_gmc_and_break_without():
+    """Static people filmed by a camera that pans 26 px per frame: every box jumps by more than its own width (24 px), so the
+    constant-velocity prediction of a freshly born track (velocity 0) has IoU 0 with the next detection.  With the frame handed
+    to update() the background motion moves the predicted boxes along and the ids persist from the first frame on; without
+    it the tracker loses every track on frame 2 and issues new ids."""
+    h, w, pan = 240, 640, 26
+    scene = ((_smooth_noise(h, w + 400, seed=21, sigma=2.0).astype(np.int32) + _smooth_noise(h, w + 400, seed=22, sigma=8.0)) // 2).astype(np.uint8)
+    people = [(60.0, 60.0), (200.0, 120.0), (330.0, 80.0)]           # box centres at frame 0, 24 x 60 px boxes
+
+    def frame_and_dets(k):
+        g = scene[:, pan * k:pan * k + w]                            # camera moved right by pan*k: the scene moves left
+        det = [[cx - pan * k - 12, cy - 30, cx - pan * k + 12, cy + 30, 0.9, 0] for cx, cy in people]
+        return np.stack([g, g, g], -1), np.asarray(det, np.float32)
+
+    with_gmc, without = BYTETracker(), BYTETracker(gmc_method=None)
+    ids_a, ids_b = [], []
+    for k in range(5):
+        img, det = frame_and_dets(k)
+        ra = with_gmc.update(det, img)
+        rb = without.update(det, img)
+        ids_a.append(sorted(ra[:, 4].astype(int).tolist()))
+        ids_b.append(sorted(rb[:, 4].astype(int).tolist()))
+    assert ids_a == [[1, 2, 3]] * 5, ids_a
+    assert ids_b[0] == [1, 2, 3] and all(set(x).isdisjoint({1, 2, 3}) for x in ids_b[2:]), ids_b
+    # the compensated boxes sit on the detections (the Kalman update then has a zero-velocity innovation)
+    last = with_gmc.update(frame_and_dets(5)[1], frame_and_dets(5)[0])
+    want = np.array([[cx - pan * 5, cy] for cx, cy in people])
+    got = np.stack([(last[:, 0] + last[:, 2]) / 2, (last[:, 1] + last[:, 3]) / 2], 1)
+    assert np.abs(np.sort(got, 0) - np.sort(want, 0)).max() < 1.0
+
+
+def test_update_without_a_frame_is_the_identity_path():
+    t1, t2 = BYTETracker(), BYTETracker(gmc_method=None)
+    det = np.asarray([[10, 10, 50, 90, 0.9, 0]], np.float32)
+    for _ in range(3):
+        np.testing.assert_array_equal(t1.update(det), t2.update(det))
+    with pytest.raises(ValueError):
+        BYTETracker(gmc_method="orb")
+
+
+def test_host_cpp_lucas_kanade_is_the_numpy_statement_of_the_algorithm():
+    """the product runs csrc/gmc_host.cpp; gmc.calc_optical_flow_pyr_lk_numpy states the same algorithm in numpy -- same points
+    kept, same positions to float32 rounding"""
+    big = ((_smooth_noise(200, 260, seed=3, sigma=2.0).astype(np.int32) + _smooth_noise(200, 260, seed=4, sigma=8.0)) // 2).astype(np.uint8)
+    prev, cur = big[20:170, 30:230], big[23:173, 25:225]
+    pts = gmc.good_features_to_track(prev)[:300]
+    a, sa = gmc.calc_optical_flow_pyr_lk(prev, cur, pts)
+    b, sb = gmc.calc_optical_flow_pyr_lk_numpy(prev, cur, pts)
+    assert (sa == sb).mean() > 0.99
+    both = sa & sb
+    assert both.sum() > 100 and np.abs(a[both] - b[both]).max() < 1e-3
+    assert gmc.calc_optical_flow_pyr_lk(prev, cur, np.zeros((0, 2), np.float32))[0].shape == (0, 2)

@@ -300,3 +300,24 @@ def test_full_size_batch_properties(v8n_pose):
         b = r.boxes.data.numpy()
         assert len(b) <= 300 and (np.diff(b[:, 4]) <= 0).all()
         assert (b[:, :4] >= 0).all() and (b[:, [0, 2]] <= 640).all() and (b[:, [1, 3]] <= 640).all()
+
+
+@pytest.mark.parametrize("name,n,size", [("yolov8n", 4, 320), ("yolov8n-pose", 1, 640), ("yolov5nu", 2, 320)])
+def test_grouped_launches_do_not_change_a_bit_and_do_not_vary(name, n, size, monkeypatch):
+    """the latency-bound regime's step schedule + grouped launches (independent convs of one DAG step as one grid) against
+    the plain program-order schedule of the same engine: identical head tensors, identical on every repetition, fewer launches"""
+    from cvsd_amd import YOLO
+    from tools import synth
+    ckpt = synth.synthetic_checkpoint(name, seed=0)
+    frames = synth.synthetic_frames(n, size, size, seed=9)
+    monkeypatch.setenv("MI355_GROUPS", "0")
+    plain = YOLO.from_state_dict(name, ckpt[1], batch_chunk=n)
+    ref = plain.raw_head(frames, imgsz=size)
+    rows_ref = plain.predict(frames, imgsz=size)
+    monkeypatch.setenv("MI355_GROUPS", "1")
+    m = YOLO.from_state_dict(name, ckpt[1], batch_chunk=n)
+    for _ in range(4):
+        np.testing.assert_array_equal(m.raw_head(frames, imgsz=size), ref)
+        for a, b in zip(m.predict(frames, imgsz=size), rows_ref):
+            np.testing.assert_array_equal(a.boxes.data.numpy(), b.boxes.data.numpy())
+    assert m.plan_info()["launches_per_pass"] < plain.plan_info()["launches_per_pass"]

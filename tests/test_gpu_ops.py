@@ -267,3 +267,40 @@ def test_nms_score_ties_are_stable():
     (rows, anchors), = ops.nms(pred, 1)
     want, idx = O.non_max_suppression(torch.from_numpy(pred), nc=1, return_idxs=True)
     np.testing.assert_array_equal(anchors, idx[0].numpy())
+
+
+GROUP_CASES = [
+    # n, h, w, cin | conv a: cout, k, stride, fused 1x1 cout (0 = none) | conv b: cout, k, stride
+    (1, 40, 40, 64, 64, 3, 1, 0, 80, 3, 1),       # two head-branch 3x3 convs (LDS-staged and split-K instances)
+    (4, 20, 20, 64, 64, 3, 1, 64, 80, 1, 1),      # Conv3x3 -> Conv1x1 fused member beside a streaming pointwise member
+    (2, 40, 40, 32, 64, 3, 2, 0, 51, 1, 1),       # stride-2 conv beside a ragged-cout (51) pointwise conv
+    (1, 80, 80, 16, 16, 3, 1, 0, 32, 3, 2),       # short K
+]
+
+
+@pytest.mark.parametrize("case", GROUP_CASES)
+def test_grouped_launch_gives_each_member_the_bits_of_its_own_launch(case):
+    """conv_f32_group.hip: two independent convs as ONE grid, every pair of menu plans (sampled), repeated: each member's output
+    equals its stand-alone launch bit for bit and does not vary between launches"""
+    from cvsd_amd import ops
+    n, h, w, cin, ca, ka, sa, c2, cb, kb, sb = case
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wa = (rng.standard_normal((ca, cin, ka, ka)) / np.sqrt(cin * ka * ka)).astype(np.float32)
+    wb = (rng.standard_normal((cb, cin, kb, kb)) / np.sqrt(cin * kb * kb)).astype(np.float32)
+    ba, bb = rng.standard_normal(ca).astype(np.float32) * 0.1, rng.standard_normal(cb).astype(np.float32) * 0.1
+    w2 = b2 = None
+    if c2:
+        w2 = (rng.standard_normal((c2, ca, 1, 1)) / np.sqrt(ca)).astype(np.float32)
+        b2 = rng.standard_normal(c2).astype(np.float32) * 0.1
+        ra = ops.conv2d_fused(x, wa, ba, w2, b2, stride=sa)
+    else:
+        ra = ops.conv2d(x, wa, ba, stride=sa)
+    rb = ops.conv2d(x, wb, bb, stride=sb)
+    _, _, na, nb = ops.conv2d_group(x, wa, ba, wb, bb, sa, sb, w2a=w2, b2a=b2)
+    assert na > 0 and nb > 0
+    for rep in range(2):
+        for pa in range(0, na, max(1, na // 8)):
+            for pb in range(0, nb, max(1, nb // 8)):
+                ya, yb, _, _ = ops.conv2d_group(x, wa, ba, wb, bb, sa, sb, pa, pb, w2a=w2, b2a=b2)
+                assert np.array_equal(ya, ra) and np.array_equal(yb, rb), (case, pa, pb, rep)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from cvsd_amd import ops
-from cvsd_amd.graph import OP_STEM, OP_SPPF_POOL, OP_UPSAMPLE, engine_program, parse_model_name
+from cvsd_amd.graph import OP_CONV, OP_STEM, OP_SPPF_POOL, OP_UPSAMPLE, engine_program, parse_model_name
 from cvsd_amd.weights import build_from_state_dict
 
 
@@ -51,6 +51,20 @@ def _dag(prog):
             if c.type != OP_STEM and c.src.buf == o.dst.buf and overlap(c.src.choff, c.src.c, o.dst.choff, o.src.c):
                 users[o.src.buf].add(j)
                 deps[j] |= {k for k in range(i) if prog.ops[k].dst.buf == o.src.buf and overlap(prog.ops[k].dst.choff, written(prog.ops[k]), o.src.choff, o.src.c)}
+    # Conv3x3 -> Conv1x1 pairs the engine may run as ONE launch (the 1x1 inside the 3x3's launch): the pair's output is then
+    # written while the 3x3 still reads its input, so the 3x3 must count as a writer / user of the 1x1's output buffer
+    head = {lv.buf for lv in prog.levels}
+    for i, o in enumerate(prog.ops):
+        if o.type != OP_CONV or prog.convs[o.conv].k != 3 or o.res is not None or o.dst.buf in head:
+            continue
+        readers = [j for j, r in enumerate(prog.ops) if j != i and r.type != OP_STEM and
+                   ((r.src.buf == o.dst.buf and overlap(r.src.choff, r.src.c, o.dst.choff, o.dst.c)) or
+                    (r.res is not None and r.res.buf == o.dst.buf and overlap(r.res.choff, r.dst.c, o.dst.choff, o.dst.c)))]
+        if len(readers) == 1 and readers[0] > i:
+            r = prog.ops[readers[0]]
+            if r.type == OP_CONV and prog.convs[r.conv].k == 1 and r.res is None and (r.src.buf, r.src.choff, r.src.c) == (o.dst.buf, o.dst.choff, o.dst.c):
+                users[r.dst.buf].add(i)
+                writers[r.dst.buf].add(i)
     anc = [set() for _ in range(n)]
     for i in range(n):
         for d in deps[i]:
