@@ -38,8 +38,10 @@ __device__ __forceinline__ float silu_f(float v) { return det_silu(v); }
 // bias + SiLU (+ residual) and the 16-byte stores: a lane holds 4 consecutive couts of one pixel per tile.
 // Two passes: all the ALU work first (16 independent SiLU chains per lane interleave freely), then the stores back to
 // back.
-template <int STRIDE, int PT, int CT, int WP>
-__device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x4 (&acc)[CT][PT], const f32x4 (&bias4)[CT], int lane, int wp,
+// KA: the argument block's type -- ConvKArgs (a kernel's own by-value parameter) or a constant-address-space view of one (a
+// member of a grouped launch reads its block from the kernarg segment on demand: conv_f32_group.hip)
+template <int STRIDE, int PT, int CT, int WP, class KA>
+__device__ __forceinline__ void conv_epilogue(const KA& a, f32x4 (&acc)[CT][PT], const f32x4 (&bias4)[CT], int lane, int wp,
                                               int ct0, int b, int oy0, int ox0, int npix) {
     if (a.act) {
 #pragma unroll
@@ -134,8 +136,8 @@ __device__ __forceinline__ void store_tile(f32x4 v, const float* bias, int act, 
 #define MI355_V1_MINWAVES 4      // min waves per SIMD asked of the register allocator for the PT*CT == 4 instances (A/B with
                                  // tools/ab_build.sh: 1 -> 4 costs a 12-byte spill outside the loop, buys 2-3 % on the stride-2 layers, 0-1 % elsewhere)
 #endif
-template <int KS, int STRIDE, int PT, int CT, int WP, bool F2 = false>
-__device__ __forceinline__ void conv_igemm_f32_body(const ConvKArgs& a, float* lds, const BlockId& bid) {
+template <int KS, int STRIDE, int PT, int CT, int WP, bool F2 = false, class KA = ConvKArgs>
+__device__ __forceinline__ void conv_igemm_f32_body(const KA& a, float* lds, const BlockId& bid) {
     constexpr int WC = 4 / WP;
     constexpr int TAPS = KS * KS;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -149,9 +151,9 @@ __device__ __forceinline__ void conv_igemm_f32_body(const ConvKArgs& a, float* l
     // tile decomposition on the scalar unit (FastDiv), per-lane products as 24-bit multiplies: the prologue's integer
     // divisions and 32/64-bit multiplies were ~50 slow vector instructions per block
     int t, cgrp0;
-    xcd_work_item(t, cgrp0, a.fd_gy, bid);
-    const int tq = (int)fastdiv((unsigned)t, a.fd_tx), tx = t - tq * a.tiles_x;
-    const int b = (int)fastdiv((unsigned)tq, a.fd_ty), ty = tq - b * a.tiles_y;
+    xcd_work_item(t, cgrp0, FastDiv{a.fd_gy.ml, a.fd_gy.mh}, bid);
+    const int tq = (int)fastdiv((unsigned)t, FastDiv{a.fd_tx.ml, a.fd_tx.mh}), tx = t - tq * a.tiles_x;
+    const int b = (int)fastdiv((unsigned)tq, FastDiv{a.fd_ty.ml, a.fd_ty.mh}), ty = tq - b * a.tiles_y;
     const int oy0 = ty * a.TH, ox0 = tx * a.TW;
     const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
     const int npix = a.TW * a.TH;
@@ -328,7 +330,7 @@ __device__ __forceinline__ void conv_igemm_f32_body(const ConvKArgs& a, float* l
         }
 
         if constexpr (!F2) {
-            conv_epilogue<STRIDE, PT, CT, WP>(a, tot, bias4, lane, wp, ct0, b, oy0, ox0, npix);
+            conv_epilogue<STRIDE, PT, CT, WP, KA>(a, tot, bias4, lane, wp, ct0, b, oy0, ox0, npix);
         } else {
             // first conv's output (bias + activation applied: the value the unfused launch would have stored) -> LDS image
             // [pixel][channel] with pixel stride ldp2, behind the halo tile; padded cout tiles (all-zero weights and bias)
@@ -422,8 +424,8 @@ __global__ __launch_bounds__(256, (PT * CT == 4 ? MI355_V1_MINWAVES : PT * CT ==
 // bit-exact BECAUSE the canonical order is blocked: a block partial is one chain from +0 whoever computes it; the partials
 // go to LDS (1 KiB per tile and block) and are then added in ascending block order, exactly as the one-wave kernels do in
 // registers.  LDS = [halo tile of one chunk | cib x CT x PT partial tiles].
-template <int KS, int STRIDE, int PT, int CT>
-__device__ __forceinline__ void conv_splitk_f32_body(const ConvKArgs& a, float* lds, const BlockId& bid) {
+template <int KS, int STRIDE, int PT, int CT, class KA = ConvKArgs>
+__device__ __forceinline__ void conv_splitk_f32_body(const KA& a, float* lds, const BlockId& bid) {
     constexpr int TAPS = KS * KS;
     static_assert(TAPS == 9, "split-K kernel is written for 3x3 convs");
     const int tid = threadIdx.x, lane = tid & 63;
@@ -580,8 +582,8 @@ __global__ __launch_bounds__(256) void conv_splitk_f32(ConvKArgs a) {
 // 4g..4g+3 of pixel p: 64 contiguous bytes per pixel per 16-channel block), with a 4-deep register prefetch ring for
 // pixels (HBM latency) and weights (L2 latency).  No LDS, no barriers: waves drift apart and overlap each other's
 // epilogues.  Same canonical accumulation order as v1 (per 16-channel block a chain from +0; partials summed in block order).
-template <int PT, int CT>
-__device__ __forceinline__ void conv1x1_stream_f32_body(const ConvKArgs& a, const BlockId& bid) {
+template <int PT, int CT, class KA = ConvKArgs>
+__device__ __forceinline__ void conv1x1_stream_f32_body(const KA& a, const BlockId& bid) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: tile bases and weight offsets stay scalar

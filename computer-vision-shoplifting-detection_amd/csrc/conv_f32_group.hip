@@ -4,6 +4,7 @@
 #include "conv_f32_inst.h"
 #include <algorithm>
 #include <cstddef>
+#include <cstdlib>
 
 namespace mi355 {
 
@@ -13,68 +14,82 @@ enum { G_IGEMM = 0, G_SPLITK = 48, G_STREAM = 56, G_KINDS = 65 };
 
 __device__ __forceinline__ int log2i(int v) { return v == 4 ? 2 : v == 2 ? 1 : 0; }
 
-#define MI355_G_IGEMM_CASES(st, f2, base)                                                                                   \
-    case base + 0:  conv_igemm_f32_body<3, st, 1, 1, 1, f2>(a, lds, bid); break;                                             \
-    case base + 1:  conv_igemm_f32_body<3, st, 1, 1, 2, f2>(a, lds, bid); break;                                             \
-    case base + 2:  conv_igemm_f32_body<3, st, 1, 1, 4, f2>(a, lds, bid); break;                                             \
-    case base + 3:  conv_igemm_f32_body<3, st, 1, 2, 1, f2>(a, lds, bid); break;                                             \
-    case base + 4:  conv_igemm_f32_body<3, st, 1, 2, 2, f2>(a, lds, bid); break;                                             \
-    case base + 5:  conv_igemm_f32_body<3, st, 1, 2, 4, f2>(a, lds, bid); break;                                             \
-    case base + 6:  conv_igemm_f32_body<3, st, 2, 1, 1, f2>(a, lds, bid); break;                                             \
-    case base + 7:  conv_igemm_f32_body<3, st, 2, 1, 2, f2>(a, lds, bid); break;                                             \
-    case base + 8:  conv_igemm_f32_body<3, st, 2, 1, 4, f2>(a, lds, bid); break;                                             \
-    case base + 9:  conv_igemm_f32_body<3, st, 2, 2, 1, f2>(a, lds, bid); break;                                             \
-    case base + 10: conv_igemm_f32_body<3, st, 2, 2, 2, f2>(a, lds, bid); break;                                             \
-    case base + 11: conv_igemm_f32_body<3, st, 2, 2, 4, f2>(a, lds, bid); break;
+typedef const __attribute__((address_space(4))) ConvKArgs KArgsC;     // an argument block in the kernarg segment (constant address space)
 
-// One member's work: its kernel instance (`kind`) on its arguments.  Force-inlined once per member SLOT, so that `a` is always a
-// by-value kernel parameter at a static offset of the kernarg segment: every field then arrives by on-demand scalar loads, exactly
-// as in the stand-alone kernels.  (A first version copied the selected member's arguments out of an array: 75 dwords loaded up
-// front, 370 SGPRs spilled to VGPR lanes -- and sporadically wrong accumulator lanes in the LDS-free streaming member.)
-__device__ __forceinline__ void run_member(const ConvKArgs& a, int kind, float* lds, const BlockId& bid) {
-    switch (kind) {
-        MI355_G_IGEMM_CASES(1, false, 0)
-        MI355_G_IGEMM_CASES(1, true, 12)
-        MI355_G_IGEMM_CASES(2, false, 24)
-        MI355_G_IGEMM_CASES(2, true, 36)
-        case G_SPLITK + 0: conv_splitk_f32_body<3, 1, 1, 1>(a, lds, bid); break;
-        case G_SPLITK + 1: conv_splitk_f32_body<3, 1, 1, 2>(a, lds, bid); break;
-        case G_SPLITK + 2: conv_splitk_f32_body<3, 1, 2, 1>(a, lds, bid); break;
-        case G_SPLITK + 3: conv_splitk_f32_body<3, 1, 2, 2>(a, lds, bid); break;
-        case G_SPLITK + 4: conv_splitk_f32_body<3, 2, 1, 1>(a, lds, bid); break;
-        case G_SPLITK + 5: conv_splitk_f32_body<3, 2, 1, 2>(a, lds, bid); break;
-        case G_SPLITK + 6: conv_splitk_f32_body<3, 2, 2, 1>(a, lds, bid); break;
-        case G_SPLITK + 7: conv_splitk_f32_body<3, 2, 2, 2>(a, lds, bid); break;
-        case G_STREAM + 0: conv1x1_stream_f32_body<1, 1>(a, bid); break;      // register tiles of at most 4 MFMA tiles: the widest
-        case G_STREAM + 1: conv1x1_stream_f32_body<1, 2>(a, bid); break;      // member sets the register count (= occupancy) of all
-        case G_STREAM + 2: conv1x1_stream_f32_body<1, 4>(a, bid); break;
-        case G_STREAM + 3: conv1x1_stream_f32_body<2, 1>(a, bid); break;
-        case G_STREAM + 4: conv1x1_stream_f32_body<2, 2>(a, bid); break;
-        case G_STREAM + 6: conv1x1_stream_f32_body<4, 1>(a, bid); break;
-        default: break;
-    }
-}
+#define MI355_G_IGEMM_CASES(st, f2, base)                                                                                   \
+    case base + 0:  conv_igemm_f32_body<3, st, 1, 1, 1, f2, KArgsC>(a, lds, bid); break;                                     \
+    case base + 1:  conv_igemm_f32_body<3, st, 1, 1, 2, f2, KArgsC>(a, lds, bid); break;                                     \
+    case base + 2:  conv_igemm_f32_body<3, st, 1, 1, 4, f2, KArgsC>(a, lds, bid); break;                                     \
+    case base + 3:  conv_igemm_f32_body<3, st, 1, 2, 1, f2, KArgsC>(a, lds, bid); break;                                     \
+    case base + 4:  conv_igemm_f32_body<3, st, 1, 2, 2, f2, KArgsC>(a, lds, bid); break;                                     \
+    case base + 5:  conv_igemm_f32_body<3, st, 1, 2, 4, f2, KArgsC>(a, lds, bid); break;                                     \
+    case base + 6:  conv_igemm_f32_body<3, st, 2, 1, 1, f2, KArgsC>(a, lds, bid); break;                                     \
+    case base + 7:  conv_igemm_f32_body<3, st, 2, 1, 2, f2, KArgsC>(a, lds, bid); break;                                     \
+    case base + 8:  conv_igemm_f32_body<3, st, 2, 1, 4, f2, KArgsC>(a, lds, bid); break;                                     \
+    case base + 9:  conv_igemm_f32_body<3, st, 2, 2, 1, f2, KArgsC>(a, lds, bid); break;                                     \
+    case base + 10: conv_igemm_f32_body<3, st, 2, 2, 2, f2, KArgsC>(a, lds, bid); break;                                     \
+    case base + 11: conv_igemm_f32_body<3, st, 2, 2, 4, f2, KArgsC>(a, lds, bid); break;
 
 #ifndef MI355_GROUP_MINWAVES
 #define MI355_GROUP_MINWAVES 4      // the widest menu instance sets every member's register count: 4 waves per SIMD = 128 registers
 #endif
-__global__ __launch_bounds__(256, MI355_GROUP_MINWAVES) void conv_group_f32(GroupHdr hdr, ConvKArgs a0, ConvKArgs a1, ConvKArgs a2) {
+// The members' argument blocks travel as by-value kernel parameters; a block reads ITS member's block straight from the kernarg
+// segment through a constant-address-space reference, field by field and on demand -- scalar loads at (uniform base + static
+// offset), the way a stand-alone kernel reads its own arguments.  Two earlier forms loaded a whole block (or all three) up
+// front: 370 - 1600 SGPR spills to VGPR lanes around the matrix instructions, and sporadically wrong accumulator lanes in the
+// streaming member whenever a split-K member shared the launch (16 floats in ~10 % of the passes; tools/dbg_stress.py).
+__global__ __launch_bounds__(256, MI355_GROUP_MINWAVES) void conv_group_f32(GroupKArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    static_assert(kGroupMax == 3, "one by-value argument block per member slot");
+    typedef const __attribute__((address_space(4))) char* KPtr;
+    const KPtr kbase = (KPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef const __attribute__((address_space(4))) GroupHdr HdrC;
+    HdrC& hdr = *(HdrC*)(kbase + offsetof(GroupKArgs, hdr));
     // member of this block: block-uniform (scalar compares on blockIdx.x)
-    const int m = (hdr.n > 2 && blockIdx.x >= hdr.base[2]) ? 2 : (hdr.n > 1 && blockIdx.x >= hdr.base[1]) ? 1 : 0;
+    int m = 0;
+#pragma unroll
+    for (int i = 1; i < kGroupMax; ++i)
+        if (i < hdr.n && blockIdx.x >= hdr.base[i]) m = i;
     const unsigned local = blockIdx.x - hdr.base[m];
     const unsigned gx = hdr.gx[m], gy = hdr.gy[m];
     if (local >= gx * gy) return;                        // padding blocks (member ranges are rounded up to multiples of 8)
     const BlockId bid{local % gx, local / gx, gx, gy};
     const int kind = hdr.kind[m];
-    if (m == 0) run_member(a0, kind, lds, bid);
-    else if (m == 1) run_member(a1, kind, lds, bid);
-    else run_member(a2, kind, lds, bid);
+    KArgsC& a = *(KArgsC*)(kbase + offsetof(GroupKArgs, a) + (size_t)m * sizeof(ConvKArgs));
+    (void)g;
+    switch (kind) {
+        MI355_G_IGEMM_CASES(1, false, 0)
+        MI355_G_IGEMM_CASES(1, true, 12)
+        MI355_G_IGEMM_CASES(2, false, 24)
+        MI355_G_IGEMM_CASES(2, true, 36)
+        case G_SPLITK + 0: conv_splitk_f32_body<3, 1, 1, 1, KArgsC>(a, lds, bid); break;
+        case G_SPLITK + 1: conv_splitk_f32_body<3, 1, 1, 2, KArgsC>(a, lds, bid); break;
+        case G_SPLITK + 2: conv_splitk_f32_body<3, 1, 2, 1, KArgsC>(a, lds, bid); break;
+        case G_SPLITK + 3: conv_splitk_f32_body<3, 1, 2, 2, KArgsC>(a, lds, bid); break;
+        case G_SPLITK + 4: conv_splitk_f32_body<3, 2, 1, 1, KArgsC>(a, lds, bid); break;
+        case G_SPLITK + 5: conv_splitk_f32_body<3, 2, 1, 2, KArgsC>(a, lds, bid); break;
+        case G_SPLITK + 6: conv_splitk_f32_body<3, 2, 2, 1, KArgsC>(a, lds, bid); break;
+        case G_SPLITK + 7: conv_splitk_f32_body<3, 2, 2, 2, KArgsC>(a, lds, bid); break;
+        case G_STREAM + 0: conv1x1_stream_f32_body<1, 1, KArgsC>(a, bid); break;      // register tiles of at most 4 MFMA tiles: the widest
+        case G_STREAM + 1: conv1x1_stream_f32_body<1, 2, KArgsC>(a, bid); break;      // member sets the register count (= occupancy) of all
+        case G_STREAM + 2: conv1x1_stream_f32_body<1, 4, KArgsC>(a, bid); break;
+        case G_STREAM + 3: conv1x1_stream_f32_body<2, 1, KArgsC>(a, bid); break;
+        case G_STREAM + 4: conv1x1_stream_f32_body<2, 2, KArgsC>(a, bid); break;
+        case G_STREAM + 6: conv1x1_stream_f32_body<4, 1, KArgsC>(a, bid); break;
+        default: break;
+    }
 }
 
 int group_kind(const ConvLaunch& l, int ks, int stride) {
+    // MI355_GROUP_MENU: bit 0 = LDS-staged 3x3, bit 1 = split-K, bit 2 = streaming pointwise, bit 3 = fused pointwise stage.
+    // The streaming pointwise instances (bit 2) are compiled in but NOT offered by default: beside a split-K member
+    // (conv_splitk_f32<3, 1, 1, 1> + conv1x1_stream_f32<2, 1>, the head's class logits beside the neck's bottleneck) the
+    // streaming member's output showed zeroed words in pixel lanes 12-15 -- in 7-100 % of the passes depending on the shape
+    // (tools/dbg_stress.py), never in isolation (mi355_op_conv2d_group passes every plan pair) and never without either
+    // family.  Cause not found; until it is, groups are formed from the LDS-staged, split-K and fused instances only, which
+    // ran clean in every stress configuration (tests/test_gpu_e2e.py::test_grouped_launches_*).
+    static const int menu = getenv("MI355_GROUP_MENU") ? atoi(getenv("MI355_GROUP_MENU")) : 11;
     const bool f2 = l.a.w2 != nullptr;
+    if ((l.version == 1 && !(menu & 1)) || (l.version == 6 && !(menu & 2)) || (l.version == 3 && !(menu & 4)) || (f2 && !(menu & 8))) return -1;
     auto lg = [](int v) { return v == 4 ? 2 : v == 2 ? 1 : v == 1 ? 0 : -1; };
     if (l.version == 1 && ks == 3 && (l.PT == 1 || l.PT == 2) && (l.CT == 1 || l.CT == 2) && lg(l.WP) >= 0 && (stride == 1 || stride == 2))
         return G_IGEMM + ((stride - 1) * 2 + (f2 ? 1 : 0)) * 12 + (l.PT - 1) * 6 + (l.CT - 1) * 3 + lg(l.WP);
@@ -110,7 +125,7 @@ const char* plan_group(const std::vector<ConvLaunch>& members, const std::vector
 }
 
 const char* run_group(const GroupLaunch& g, hipStream_t st) {
-    hipLaunchKernelGGL(conv_group_f32, dim3(g.grid), dim3(256), g.lds, st, g.k.hdr, g.k.a[0], g.k.a[1], g.k.a[2]);
+    hipLaunchKernelGGL(conv_group_f32, dim3(g.grid), dim3(256), g.lds, st, g.k);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }

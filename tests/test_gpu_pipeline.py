@@ -14,7 +14,8 @@ def _dataset(root, n_frames=6):
     for k, label in enumerate(("Shoplifting", "Shopping")):
         os.makedirs(os.path.join(root, label), exist_ok=True)
         name = f"{label}00{k + 1}_x264"
-        np.save(os.path.join(root, label, name + ".npy"), synth.synthetic_frames(n_frames, 240, 320, seed=60 + k))
+        # a CLIP (one drifting scene), not unrelated frames: the tracker compensates camera motion between consecutive frames
+        np.save(os.path.join(root, label, name + ".npy"), synth.synthetic_clip(n_frames, 240, 320, seed=60 + k))
         lines.append(f"{label}/{name}.mp4")
     lst = os.path.join(root, "list.txt")
     with open(lst, "w") as f:
@@ -95,7 +96,7 @@ def test_pose_clip_to_poselift_pickle(v8n_pose, tmp_path):
     from cvsd_amd.poselift_bridge import video_to_poselift
     from tools import synth
     m = YOLO.from_state_dict("yolov8n-pose", v8n_pose[1])
-    frames = synth.synthetic_frames(10, 240, 320, seed=77)
+    frames = synth.synthetic_clip(10, 240, 320, seed=77)          # consecutive frames of one scene (GMC + tracker need a video)
     out = str(tmp_path / "Shoplifting001.pkl")
     data = video_to_poselift(m, list(frames), out_path=out, conf=0.25, batch=4)
     with open(out, "rb") as f:
