@@ -272,8 +272,8 @@ def test_nms_score_ties_are_stable():
 GROUP_CASES = [
     # n, h, w, cin | conv a: cout, k, stride, fused 1x1 cout (0 = none) | conv b: cout, k, stride
     (1, 40, 40, 64, 64, 3, 1, 0, 80, 3, 1),       # two head-branch 3x3 convs (LDS-staged and split-K instances)
-    (4, 20, 20, 64, 64, 3, 1, 64, 80, 1, 1),      # Conv3x3 -> Conv1x1 fused member beside a streaming pointwise member
-    (2, 40, 40, 32, 64, 3, 2, 0, 51, 1, 1),       # stride-2 conv beside a ragged-cout (51) pointwise conv
+    (4, 20, 20, 64, 64, 3, 1, 64, 80, 3, 1),      # Conv3x3 -> Conv1x1 fused member beside a plain 3x3 member
+    (2, 40, 40, 32, 64, 3, 2, 0, 51, 3, 1),       # stride-2 conv beside a ragged-cout (51) conv
     (1, 80, 80, 16, 16, 3, 1, 0, 32, 3, 2),       # short K
 ]
 

