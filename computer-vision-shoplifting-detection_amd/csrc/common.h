@@ -31,6 +31,11 @@ struct ConvArgs {
     // conv's own dst is then not written (its only reader is that 1x1).  f2_cout = 0: no fusion.
     const float* f2_wpk = nullptr; const float* f2_bias = nullptr; float* f2_dst = nullptr; int f2_dst_cs = 0, f2_cout = 0, f2_act = 0;
     int f2_out_f32 = 0;                // half=True: the fused pointwise conv writes fp32 (head outputs)
+    // fp32: the fused pointwise conv reads f2_lead_c MORE input channels in FRONT of this conv's output (C2f.cv2 over cat(ys):
+    // the earlier slices of the concat buffer), from f2_lead (same resolution as this conv's output, pixel stride f2_lead_cs);
+    // f2_lead_c is a multiple of 16 and f2_wpk is packed for f2_lead_c + Cout input channels.  0: the pointwise conv reads
+    // exactly this conv's output.
+    const float* f2_lead = nullptr; int f2_lead_cs = 0, f2_lead_c = 0;
 };
 // number of floats pack_conv_weights writes: ceil(cout/16) * k*k * ceil(cin/16) * 256
 size_t packed_weight_floats(int cout, int cin, int k);
@@ -75,6 +80,7 @@ struct ConvKArgs {
     int cgroups;               // conv_igemm_f32: groups of CT cout tiles a wave walks over one staged input (>= 1)
     // conv_igemm_f32 / conv_igemm_f16 <..., F2 = true>: the pointwise conv fused behind this one (packed weights, bias, destination slice)
     const float* w2; const float* bias2; float* dst2; int dst2_cs, Cout2, n_ctiles2, cib2, act2, ldp2, out2_f32;
+    const float* lead; int lead_cs, lead_cib;   // fused pointwise stage: its first lead_cib k-blocks come from this slice in global memory (cib2 counts them)
     int n_tiles_total;         // B * tiles_x * tiles_y (persistent kernels walk tiles blockIdx.x, + gridDim.x, ...)
     FastDiv fd_tx, fd_ty, fd_gy;   // conv_igemm_f32: scalar division by tiles_x, tiles_y, gridDim.y
     int img_src, img_dst, img_res; // conv_igemm_f32: elements per image of the source / destination / residual slices' buffers (H * W * cs)

@@ -335,16 +335,31 @@ __device__ __forceinline__ void conv_igemm_f32_body(const KA& a, float* lds, con
             // first conv's output (bias + activation applied: the value the unfused launch would have stored) -> LDS image
             // [pixel][channel] with pixel stride ldp2, behind the halo tile; padded cout tiles (all-zero weights and bias)
             // give exact zeros, which is what the second conv's padded k-blocks expect
+            // The first conv may carry the Bottleneck's residual (C2f / C3 with shortcut): y = silu(tot + bias) + residual, read
+            // through a descriptor over this image of the residual slice (pixels outside the tile / image read zeros).
             float* y1 = lds + a.lds_buf_floats;
+            const __amdgpu_buffer_rsrc_t rrs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res + (size_t)b * (size_t)a.img_res : a.dst), 0,
+                                                                                  a.res ? (int)((unsigned)a.img_res * 4u) : 0, 0x00020000);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+            for (int pt = 0; pt < PT; ++pt) {
+                unsigned rvo = 0x80000000u;
+                if (a.res) {
+                    const int p = (wp * PT + pt) * 16 + (lane & 15);
+                    const int pp = p < npix ? p : 0;
+                    const int ly = (int)(((float)pp + 0.5f) * a.inv_TW);
+                    const int lx = pp - __mul24(ly, a.TW);
+                    const int oy = oy0 + ly, ox = ox0 + lx;
+                    if ((p < npix) && (oy < a.Hout) && (ox < a.Wout)) rvo = (unsigned)__mul24(__mul24(oy, a.Wout) + ox, a.res_cs) * 4u + (unsigned)(lane >> 4) * 16u;
+                }
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) {
+                for (int ct = 0; ct < CT; ++ct) {
                     if (ct0 + ct >= a.n_ctiles) continue;
                     f32x4 v = tot[ct][pt] + bias4[ct];
                     if (a.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                    if (a.res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs1, (int)rvo, (ct0 + ct) * 64, 0));
                     *(f32x4*)(y1 + ((wp * PT + pt) * 16 + (lane & 15)) * a.ldp2 + (ct0 + ct) * 16 + (lane >> 4) * 4) = v;
                 }
+            }
         }
     }
     if constexpr (F2) {
@@ -357,7 +372,15 @@ __device__ __forceinline__ void conv_igemm_f32_body(const KA& a, float* lds, con
         const int img2 = a.Hout * a.Wout * a.dst2_cs;
         const __amdgpu_buffer_rsrc_t drs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dst2 + (size_t)b * (size_t)img2), 0, (int)((unsigned)img2 * 4u), 0x00020000);
         const __amdgpu_buffer_rsrc_t wrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, 0x7fffffff, 0x00020000);
-        int x2off[PT]; unsigned dvo[PT];
+        // The pointwise conv may read MORE input channels than the first conv produced (C2f.cv2 over cat(ys): the last
+        // Bottleneck's output is the block's LDS image, the earlier slices of the concat buffer are the `lead` channels in
+        // front of it): its first a.lead_cib k-blocks come straight from global memory in the MFMA B-operand layout (lane (p, g):
+        // 16 bytes of pixel p, channels 16 kb + 4 g -- a pointwise conv needs no halo), the remaining ones from the LDS image.
+        // Blocks in ascending order as in the stand-alone launch: the same chain per block, the same sum of partials.
+        const int img_lead = a.Hout * a.Wout * a.lead_cs;
+        const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.lead_cib ? a.lead + (size_t)b * (size_t)img_lead : a.dst2), 0,
+                                                                             a.lead_cib ? (int)((unsigned)img_lead * 4u) : 0, 0x00020000);
+        int x2off[PT]; unsigned dvo[PT], lvo[PT];
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
             const int p = (wp * PT + pt) * 16 + (lane & 15);
@@ -367,20 +390,21 @@ __device__ __forceinline__ void conv_igemm_f32_body(const KA& a, float* lds, con
             const int lx = pp - __mul24(ly, a.TW);
             const int oy = oy0 + ly, ox = ox0 + lx;
             const bool ok = (p < npix) && (oy < a.Hout) && (ox < a.Wout);
-            dvo[pt] = ok ? (unsigned)__mul24(__mul24(oy, a.Wout) + ox, a.dst2_cs) * 4u + (unsigned)(lane >> 4) * 16u : 0x80000000u;
+            const int pix = __mul24(oy, a.Wout) + ox;
+            dvo[pt] = ok ? (unsigned)__mul24(pix, a.dst2_cs) * 4u + (unsigned)(lane >> 4) * 16u : 0x80000000u;
+            lvo[pt] = ok ? (unsigned)__mul24(pix, a.lead_cs) * 4u + (unsigned)(lane >> 4) * 16u : 0x80000000u;
         }
+        const int nlead = a.lead_cib;
         for (int ct2 = wc; ct2 < a.n_ctiles2; ct2 += WC) {
             const int wb = ct2 * a.cib2 * 256;                           // floats from a.w2, wave-uniform
             f32x4 tot2[PT];
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) tot2[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             f32x4 w_cur = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs2, (int)lane16, wb * 4, 0));
-            for (int cb = 0; cb < a.cib2; ++cb) {
+            auto block = [&](const f32x4 (&x2)[PT], int cb) {           // one 16-channel block: chain from +0, partial added to the sum
                 const int cn = cb + 1 < a.cib2 ? cb + 1 : cb;
                 const f32x4 w_nxt = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs2, (int)lane16, (wb + cn * 256) * 4, 0));
-                f32x4 x2[PT], p2[PT];
-#pragma unroll
-                for (int pt = 0; pt < PT; ++pt) x2[pt] = *(const f32x4*)__builtin_assume_aligned(y1 + x2off[pt] + cb * 16, 16);
+                f32x4 p2[PT];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -389,6 +413,31 @@ __device__ __forceinline__ void conv_igemm_f32_body(const KA& a, float* lds, con
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt) tot2[pt] += p2[pt];
                 w_cur = w_nxt;
+            };
+            if (nlead > 0) {
+                // lead blocks: two register sets, the next block's pixels in flight while this one's MFMAs run (loads past the
+                // last lead block re-read it: unconditional, so the waits stay counted)
+                auto load_lead = [&](f32x4 (&x)[PT], int cb) {
+                    const int k = cb < nlead ? cb : nlead - 1;
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) x[pt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)lvo[pt], k * 64, 0));
+                };
+                f32x4 xa[PT], xb[PT];
+                load_lead(xa, 0);
+                int cb = 0;
+                for (; cb + 2 <= nlead; cb += 2) {
+                    load_lead(xb, cb + 1);
+                    block(xa, cb);
+                    load_lead(xa, cb + 2);
+                    block(xb, cb + 1);
+                }
+                if (cb < nlead) block(xa, cb);
+            }
+            for (int cb = nlead; cb < a.cib2; ++cb) {
+                f32x4 x2[PT];
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) x2[pt] = *(const f32x4*)__builtin_assume_aligned(y1 + x2off[pt] + (cb - nlead) * 16, 16);
+                block(x2, cb);
             }
             const int c0t = ct2 * 16, c = c0t + (lane >> 4) * 4;
             const f32x4 bias2 = *(const f32x4*)(a.bias2 + c);            // the bias array is padded to whole cout tiles

@@ -268,6 +268,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
         a.w2 = c.f2_wpk; a.bias2 = c.f2_bias; a.dst2 = c.f2_dst; a.dst2_cs = c.f2_dst_cs; a.Cout2 = c.f2_cout; a.act2 = c.f2_act;
         a.n_ctiles2 = (c.f2_cout + 15) / 16; a.cib2 = (c.Cout + 15) / 16; a.ldp2 = round_up(c.Cout, 16) + 4;
         if (half) { a.cib2 = (c.Cout + 31) / 32; a.ldp2 = 32 * a.cib2 + 8; a.out2_f32 = c.f2_out_f32; }
+        if (c.f2_lead_c) { a.lead = c.f2_lead; a.lead_cs = c.f2_lead_cs; a.lead_cib = c.f2_lead_c / 16; a.cib2 += a.lead_cib; }
     }
     if (half && p.version == 4) a.lds_buf_floats = 0;
     if (half && p.version == 1 && !p.f2) { static const int ex = env_int("MI355_F16_EXP", 0); a.lds_buf_floats = ex; }
@@ -313,7 +314,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
         // such a plan is not offered (the streaming / pipelined pointwise kernels use per-block descriptors and remain).
         const long long lim = 1ll << 29;
         const long long e_src = (long long)a.Hin * a.Win * a.src_cs, e_dst = (long long)a.Hout * a.Wout * std::max(a.dst_cs, a.res_cs);
-        const long long e_dst2 = p.f2 ? (long long)a.Hout * a.Wout * a.dst2_cs : 0;
+        const long long e_dst2 = p.f2 ? (long long)a.Hout * a.Wout * std::max(a.dst2_cs, a.lead_cs) : 0;
         if (e_src >= lim || e_dst >= lim || e_dst2 >= lim) return "conv: image too large for the 32-bit offsets of conv_igemm_f32";
     }
     a.img_src = a.Hin * a.Win * a.src_cs; a.img_dst = a.Hout * a.Wout * a.dst_cs; a.img_res = a.Hout * a.Wout * a.res_cs;
@@ -328,7 +329,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
         out->lds = 0;
         out->a.tiles_x = (int)out->grid_x;
     }
-    out->flops = 2.0 * c.B * c.Hout * c.Wout * (double)c.Cout * (c.Cin * c.k * c.k + (p.f2 ? c.f2_cout : 0));
+    out->flops = 2.0 * c.B * c.Hout * c.Wout * ((double)c.Cout * c.Cin * c.k * c.k + (p.f2 ? (double)c.f2_cout * (c.Cout + c.f2_lead_c) : 0.0));
     return nullptr;
 }
 
@@ -341,9 +342,11 @@ const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out
     if (c.f2_cout) {
         const bool wide2 = half && !c.f2_out_f32 && conv_f16_pairs(c.f2_cout);      // 16-byte fp16 stores of the second stage
         const int cs_mask = wide2 ? 7 : 3, ptr_mask = (!half || wide2 || c.f2_out_f32) ? 15 : 7;
-        if (c.k != 3 || c.res || !c.f2_wpk || !c.f2_bias || !c.f2_dst || (c.f2_dst_cs & cs_mask) || ((uintptr_t)c.f2_dst & ptr_mask) ||
+        if (c.k != 3 || (half && c.res) || !c.f2_wpk || !c.f2_bias || !c.f2_dst || (c.f2_dst_cs & cs_mask) || ((uintptr_t)c.f2_dst & ptr_mask) ||
             (half && c.out_f32))
-            return "conv: a fused pointwise stage needs a 3x3 conv without residual and aligned second-stage buffers";
+            return "conv: a fused pointwise stage needs a 3x3 conv (half=True: without residual) and aligned second-stage buffers";
+        if (c.f2_lead_c && (half || (c.f2_lead_c & 15) || (c.Cout & 15) || !c.f2_lead || (c.f2_lead_cs & 3) || ((uintptr_t)c.f2_lead & 15)))
+            return "conv: lead channels of a fused pointwise stage must be whole 16-channel blocks of an aligned fp32 slice";
     }
     const std::vector<Plan> plans = enumerate_plans(H, W, c.k == 1 ? 1 : c.B, (c.Cout + 15) / 16, half ? (c.Cin + 1) / 2 : c.Cin, c.k,
                                                     c.stride, c.zeros != nullptr, half, c.f2_cout ? round_up(c.Cout, 16) : 0);

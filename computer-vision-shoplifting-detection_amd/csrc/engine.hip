@@ -152,6 +152,10 @@ struct mi355_yolo {
     // of every head branch.  Decided from the program at load time, confirmed per shape (a fused launch plan must exist);
     // skip_op[j] = the pointwise op j runs inside its producer's launch.  MI355_FUSE_1X1=0 disables it.
     std::vector<int> fuse2; std::vector<char> skip_op;
+    // ... and its generalisation to the tail of a C2f block: the LAST Bottleneck's second 3x3 conv (with its residual) feeds only
+    // C2f.cv2, a pointwise conv over cat(ys) whose input slice ENDS with that conv's output: fuse2_lead[i] = the channels of the
+    // concat buffer in front of it (read by the fused pointwise stage straight from global memory), 0 = exact-slice pairs.
+    std::vector<int> fuse2_lead;
     // Small chunks leave most of the chip idle inside one conv launch, but the graph has independent branches (the box / class /
     // keypoint chains of the three head levels run beside the rest of the neck): ops are dealt to a few HIP streams along the
     // program's dependency DAG (RAW on buffer slices), in depth order, a chain inheriting its producer's stream; an op waits
@@ -363,12 +367,14 @@ static int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
             h->fuse_up[reader] = (int)i; h->fused_away[i] = 1;
         }
     }
-    h->fuse2.assign(h->ops.size(), -1); h->skip_op.assign(h->ops.size(), 0);
+    h->fuse2.assign(h->ops.size(), -1); h->skip_op.assign(h->ops.size(), 0); h->fuse2_lead.assign(h->ops.size(), 0);
     const char* f2env = getenv("MI355_FUSE_1X1");
+    const char* f3env = getenv("MI355_FUSE_TAIL");
+    const bool fuse_tail = (!f3env || atoi(f3env) != 0) && !h->half;      // fp32 kernels only
     if (!f2env || atoi(f2env) != 0) {
         for (size_t i = 0; i < h->ops.size(); ++i) {
             const FileOp& p3 = h->ops[i];
-            if (p3.type != OP_CONV || h->convs[p3.conv].k != 3 || p3.res_buf >= 0) continue;
+            if (p3.type != OP_CONV || h->convs[p3.conv].k != 3 || (p3.res_buf >= 0 && !fuse_tail)) continue;
             bool is_head = false;
             for (const FileLevel& lv : h->levels) is_head |= ((int)lv.buf == p3.dst_buf);
             if (is_head) continue;
@@ -383,8 +389,13 @@ static int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
             if (n_readers != 1 || reader <= (int)i) continue;
             const FileOp& p1 = h->ops[reader];
             if (p1.type != OP_CONV || h->convs[p1.conv].k != 1 || h->convs[p1.conv].s != 1 || p1.res_buf >= 0) continue;
-            if (p1.src_choff != p3.dst_choff || p1.src_c != p3.dst_c || h->fuse_up[reader] >= 0) continue;   // reads exactly that slice
-            h->fuse2[i] = reader;
+            if (h->fuse_up[reader] >= 0 || p1.src_buf != p3.dst_buf) continue;
+            const int lead = p3.dst_choff - p1.src_choff;
+            const bool exact = lead == 0 && p1.src_c == p3.dst_c;                                   // reads exactly that slice
+            const bool tail = fuse_tail && lead > 0 && (lead % 16) == 0 && (p3.dst_c % 16) == 0 && h->convs[p3.conv].s == 1 &&
+                              p1.src_choff + p1.src_c == p3.dst_choff + p3.dst_c;                    // its input slice ENDS with that slice
+            if (!(exact && p3.res_buf < 0) && !(fuse_tail && (exact || tail))) continue;
+            h->fuse2[i] = reader; h->fuse2_lead[i] = exact ? 0 : lead;
         }
     }
     if (!h->host_only) {
@@ -423,6 +434,10 @@ static int build_schedule(mi355_yolo* h) {
         if (h->fuse_up[i] >= 0) {                   // may read the upsample's source directly (fused) or its output (not fused)
             const FileOp& u = h->ops[h->fuse_up[i]];
             add_readers_deps(i, u.src_buf, u.src_choff, u.src_c);
+        }
+        if (h->fuse2[i] >= 0 && h->fuse2_lead[i] > 0) {      // its fused pointwise stage reads the lead slices of the concat buffer
+            const FileOp& p1 = h->ops[h->fuse2[i]];
+            add_readers_deps(i, p1.src_buf, p1.src_choff, h->fuse2_lead[i]);
         }
         std::sort(deps[i].begin(), deps[i].end());
         deps[i].erase(std::unique(deps[i].begin(), deps[i].end()), deps[i].end());
@@ -705,6 +720,7 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
             f.f2_wpk = h->dconv[o1.conv].wpk; f.f2_bias = h->dconv[o1.conv].bias;
             f.f2_dst = h->view(o1.dst_buf, o1.dst_choff); f.f2_dst_cs = h->dbuf_cs[o1.dst_buf]; f.f2_cout = c1.cout; f.f2_act = c1.act;
             f.f2_out_f32 = (h->half && h->dbuf_es[o1.dst_buf] == 4) ? 1 : 0;
+            if (h->fuse2_lead[i] > 0) { f.f2_lead = h->view(o1.src_buf, o1.src_choff); f.f2_lead_cs = h->dbuf_cs[o1.src_buf]; f.f2_lead_c = h->fuse2_lead[i]; }
             if (plan_conv_candidates(f, &cands_f[i]) != nullptr) cands_f[i].clear();
             if (cands_f[i].size() > top) cands_f[i].resize(top);
         }
@@ -1668,7 +1684,7 @@ int mi355_op_conv2d_f16(int device_id, const float* x, int n, int h, int w, int 
 // hook of the fused pairs the engine runs (stride-2 conv -> C2f.cv1, head branch [1] -> [2]).
 static int op_conv2d_fused_impl(int device_id, const float* x, int n, int h, int w, int cin, const float* w1_oihw, const float* b1, int c1,
                                 int stride, const float* w2_oihw, const float* b2, int c2, int silu2, float* y, int plan_index, int* n_plans,
-                                bool half, bool out_f32) {
+                                bool half, bool out_f32, const float* residual = nullptr, const float* lead = nullptr, int lead_c = 0) {
     if (!x || !w1_oihw || !b1 || !w2_oihw || !b2 || !y || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || c1 <= 0 || c2 <= 0) return fail(MI355_EINVAL, "bad argument");
     if ((stride != 1 && stride != 2) || (h % stride) || (w % stride)) return fail(MI355_EINVAL, "stride must be 1 or 2 and divide h and w");
     HIPCHK(hipSetDevice(device_id));
@@ -1706,10 +1722,27 @@ static int op_conv2d_fused_impl(int device_id, const float* x, int n, int h, int
         HIPCHK(dm.alloc(db, bp.size() * 4)); HIPCHK(hipMemcpy(*db, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
         return MI355_OK;
     };
+    if ((residual || lead_c) && half) return fail(MI355_EINVAL, "residual / lead channels exist in the fp32 fused kernel only");
+    if (lead_c < 0 || (lead_c > 0 && !lead)) return fail(MI355_EINVAL, "bad lead argument");
     int rc = upload_conv(w1_oihw, b1, c1, cin, 3, &d_w1, &d_b1); if (rc) return rc;
-    rc = upload_conv(w2_oihw, b2, c2, c1, 1, &d_w2, &d_b2); if (rc) return rc;
+    rc = upload_conv(w2_oihw, b2, c2, lead_c + c1, 1, &d_w2, &d_b2); if (rc) return rc;       // pointwise weights over cat(lead, conv1 output)
     ConvArgs a{};
-    a.src = d_x; a.src_cs = cs_in; a.dst = d_mid; a.dst_cs = cs_mid; a.wpk = d_w1; a.bias = d_b1; a.zeros = d_z;
+    // lead channels and the first conv's (unused) destination share ONE buffer [lead | mid], as the C2f concat buffer does
+    float* d_cat = nullptr; float* d_res = nullptr;
+    const int cs_cat = round_up(lead_c + c1, 4);
+    if (lead_c) {
+        std::vector<float> cat(npo * cs_cat, 0.f);
+        for (size_t p = 0; p < npo; ++p) std::memcpy(&cat[p * cs_cat], lead + p * lead_c, (size_t)lead_c * 4);
+        HIPCHK(dm.alloc(&d_cat, cat.size() * 4)); HIPCHK(hipMemcpy(d_cat, cat.data(), cat.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (residual) {
+        std::vector<float> rs(npo * cs_mid, 0.f);
+        for (size_t p = 0; p < npo; ++p) std::memcpy(&rs[p * cs_mid], residual + p * c1, (size_t)c1 * 4);
+        HIPCHK(dm.alloc(&d_res, rs.size() * 4)); HIPCHK(hipMemcpy(d_res, rs.data(), rs.size() * 4, hipMemcpyHostToDevice));
+        a.res = d_res; a.res_cs = cs_mid;
+    }
+    if (lead_c) { a.f2_lead = d_cat; a.f2_lead_cs = cs_cat; a.f2_lead_c = lead_c; }
+    a.src = d_x; a.src_cs = cs_in; a.dst = lead_c ? d_cat + lead_c : d_mid; a.dst_cs = lead_c ? cs_cat : cs_mid; a.wpk = d_w1; a.bias = d_b1; a.zeros = d_z;
     a.B = n; a.Hin = h; a.Win = w; a.Hout = ho; a.Wout = wo; a.Cin = cin; a.Cout = c1; a.k = 3; a.stride = stride; a.pad = 1; a.act = 1;
     a.dtype = half ? 1 : 0;
     a.f2_wpk = d_w2; a.f2_bias = d_b2; a.f2_dst = d_y; a.f2_dst_cs = cs_out; a.f2_cout = c2; a.f2_act = silu2 ? 1 : 0;
@@ -1798,6 +1831,13 @@ int mi355_op_conv2d_group(int device_id, const float* x, int n, int h, int w, in
 int mi355_op_conv2d_fused(int device_id, const float* x, int n, int h, int w, int cin, const float* w1_oihw, const float* b1, int c1,
                           int stride, const float* w2_oihw, const float* b2, int c2, int silu2, float* y, int plan_index, int* n_plans) {
     return op_conv2d_fused_impl(device_id, x, n, h, w, cin, w1_oihw, b1, c1, stride, w2_oihw, b2, c2, silu2, y, plan_index, n_plans, false, false);
+}
+
+int mi355_op_c2f_tail(int device_id, const float* x, int n, int h, int w, int cin, const float* w1_oihw, const float* b1, int c1,
+                      const float* residual, const float* lead, int lead_c, const float* w2_oihw, const float* b2, int c2, float* y,
+                      int plan_index, int* n_plans) {
+    return op_conv2d_fused_impl(device_id, x, n, h, w, cin, w1_oihw, b1, c1, 1, w2_oihw, b2, c2, 1, y, plan_index, n_plans, false, false,
+                                residual, lead, lead_c);
 }
 
 int mi355_op_conv2d_fused_f16(int device_id, const float* x, int n, int h, int w, int cin, const float* w1_oihw, const float* b1, int c1,

@@ -162,3 +162,25 @@ def conv2d_group(x_nhwc: np.ndarray, wa: np.ndarray, ba: np.ndarray, wb: np.ndar
                                                 yb.ctypes.data, int(plan_a), int(plan_b), C.byref(na), C.byref(nb),
                                                 w2a.ctypes.data if c2 else None, b2a.ctypes.data if c2 else None, c2))
     return ya, yb, na.value, nb.value
+
+
+def c2f_tail(x_nhwc: np.ndarray, w1: np.ndarray, b1: np.ndarray, lead: np.ndarray, w2: np.ndarray, b2: np.ndarray,
+             residual: Optional[np.ndarray] = None, device: int = 0, plan: int = 0, return_n_plans: bool = False):
+    """The tail of a C2f block as one fused launch: SiLU(conv1x1(cat(lead, SiLU(conv3x3(x) + b1) + residual)) + b2).
+    x [N,H,W,Cin], lead [N,H,W,L] (L and the 3x3's cout multiples of 16), w2 [C2, L + C1, 1, 1]."""
+    x, w1, b1, lead, w2, b2 = _f32(x_nhwc), _f32(w1), _f32(b1), _f32(lead), _f32(w2), _f32(b2)
+    n, h, wd, cin = x.shape
+    c1, c2, L = w1.shape[0], w2.shape[0], lead.shape[-1]
+    if w1.shape != (c1, cin, 3, 3) or w2.shape != (c2, L + c1, 1, 1) or lead.shape[:3] != (n, h, wd):
+        raise ValueError("shape mismatch")
+    r = None
+    if residual is not None:
+        r = _f32(residual)
+        if r.shape != (n, h, wd, c1):
+            raise ValueError("residual must have the 3x3 conv's output shape")
+    y = np.empty((n, h, wd, c2), dtype=np.float32)
+    npl = C.c_int(0)
+    _lib.check(_lib.lib().mi355_op_c2f_tail(device, x.ctypes.data, n, h, wd, cin, w1.ctypes.data, b1.ctypes.data, c1,
+                                            r.ctypes.data if r is not None else None, lead.ctypes.data, L, w2.ctypes.data, b2.ctypes.data, c2,
+                                            y.ctypes.data, int(plan), C.byref(npl)))
+    return (y, npl.value) if return_n_plans else y

@@ -180,6 +180,13 @@ int  mi355_op_conv2d_f16(int device_id, const float* x, int n, int h, int w, int
 int  mi355_op_conv2d_fused(int device_id, const float* x, int n, int h, int w, int cin, const float* w1_oihw, const float* b1,
                            int c1, int stride, const float* w2_oihw, const float* b2, int c2, int silu2, float* y,
                            int plan_index, int* n_plans);
+/* The tail of a C2f block as ONE fused launch (fp32): the last Bottleneck's second conv, y1 = SiLU(conv3x3(x) + b1) + residual,
+ * and C2f.cv2 over the concatenation, y = SiLU(conv1x1(cat(lead, y1)) + b2) -- lead[n][h][w][lead_c] are the earlier slices of
+ * the block's concat buffer (lead_c a multiple of 16, as is c1), w2[c2][lead_c + c1][1][1]; residual (or NULL) [n][h][w][c1].
+ * Must equal mi355_op_conv2d (3x3, residual) followed by mi355_op_conv2d (1x1 on the concatenation), bit for bit, for every plan. */
+int  mi355_op_c2f_tail(int device_id, const float* x, int n, int h, int w, int cin, const float* w1_oihw, const float* b1, int c1,
+                       const float* residual, const float* lead, int lead_c, const float* w2_oihw, const float* b2, int c2,
+                       float* y, int plan_index, int* n_plans);
 /* The same fused pair on the half=True path (operands rounded to fp16 on the way in, the intermediate image rounded to fp16 as the
  * unfused launch would have stored it, fp32 accumulation; out_f32 = 1: y written as fp32, as for the head's final convs): must
  * equal mi355_op_conv2d_f16 of the 3x3 conv followed by mi355_op_conv2d_f16 of the 1x1, bit for bit, for every plan_index. */

@@ -304,3 +304,35 @@ def test_grouped_launch_gives_each_member_the_bits_of_its_own_launch(case):
             for pb in range(0, nb, max(1, nb // 8)):
                 ya, yb, _, _ = ops.conv2d_group(x, wa, ba, wb, bb, sa, sb, pa, pb, w2a=w2, b2a=b2)
                 assert np.array_equal(ya, ra) and np.array_equal(yb, rb), (case, pa, pb, rep)
+
+
+C2F_TAIL_CASES = [
+    # n, h, w, cin, c1 (3x3 cout), lead channels, c2 (1x1 cout), residual
+    (2, 24, 20, 16, 16, 32, 32, True),        # model.2 of YOLOv8n: cat(ys) = 48 channels, the last 16 stay in LDS
+    (1, 20, 20, 64, 64, 128, 128, True),      # model.6-like
+    (2, 17, 13, 32, 32, 64, 64, False),       # neck C2f (no shortcut), odd image size
+    (1, 9, 11, 48, 48, 96, 51, True),         # YOLOv8m widths, ragged pointwise cout
+    (3, 8, 8, 16, 16, 48, 32, True),          # two Bottlenecks in front (lead = 3 slices)
+]
+
+
+@pytest.mark.parametrize("case", C2F_TAIL_CASES)
+def test_c2f_tail_fused_launch_equals_the_two_convs(case):
+    """Bottleneck.cv2 (3x3 + residual) -> C2f.cv2 (1x1 over cat(ys)) as one launch: the pointwise stage reads the earlier concat
+    slices from global memory and the last one from the block's LDS image -- bit for bit the two separate launches, every plan"""
+    from cvsd_amd import ops
+    n, h, w, cin, c1, L, c2, res = case
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    lead = rng.standard_normal((n, h, w, L)).astype(np.float32)
+    w1 = (rng.standard_normal((c1, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+    w2 = (rng.standard_normal((c2, L + c1, 1, 1)) / np.sqrt(L + c1)).astype(np.float32)
+    b1, b2 = rng.standard_normal(c1).astype(np.float32) * 0.1, rng.standard_normal(c2).astype(np.float32) * 0.1
+    r = rng.standard_normal((n, h, w, c1)).astype(np.float32) if res else None
+    y1 = ops.conv2d(x, w1, b1, residual=r)
+    want = ops.conv2d(np.concatenate([lead, y1], axis=-1), w2, b2)
+    got, npl = ops.c2f_tail(x, w1, b1, lead, w2, b2, residual=r, return_n_plans=True)
+    assert npl >= 1
+    np.testing.assert_array_equal(got, want)
+    for k in range(1, npl):
+        np.testing.assert_array_equal(ops.c2f_tail(x, w1, b1, lead, w2, b2, residual=r, plan=k), want)

@@ -55,16 +55,22 @@ def _dag(prog):
     # written while the 3x3 still reads its input, so the 3x3 must count as a writer / user of the 1x1's output buffer
     head = {lv.buf for lv in prog.levels}
     for i, o in enumerate(prog.ops):
-        if o.type != OP_CONV or prog.convs[o.conv].k != 3 or o.res is not None or o.dst.buf in head:
+        if o.type != OP_CONV or prog.convs[o.conv].k != 3 or o.dst.buf in head:
             continue
         readers = [j for j, r in enumerate(prog.ops) if j != i and r.type != OP_STEM and
                    ((r.src.buf == o.dst.buf and overlap(r.src.choff, r.src.c, o.dst.choff, o.dst.c)) or
                     (r.res is not None and r.res.buf == o.dst.buf and overlap(r.res.choff, r.dst.c, o.dst.choff, o.dst.c)))]
         if len(readers) == 1 and readers[0] > i:
             r = prog.ops[readers[0]]
-            if r.type == OP_CONV and prog.convs[r.conv].k == 1 and r.res is None and (r.src.buf, r.src.choff, r.src.c) == (o.dst.buf, o.dst.choff, o.dst.c):
+            exact = (r.src.buf, r.src.choff, r.src.c) == (o.dst.buf, o.dst.choff, o.dst.c)
+            # ... or the tail of a C2f block: C2f.cv2 reads cat(ys), whose LAST slice is this Bottleneck conv's output
+            tail = (r.src.buf == o.dst.buf and r.src.choff < o.dst.choff and r.src.choff + r.src.c == o.dst.choff + o.dst.c
+                    and (o.dst.choff - r.src.choff) % 16 == 0 and o.dst.c % 16 == 0 and prog.convs[o.conv].s == 1)
+            if r.type == OP_CONV and prog.convs[r.conv].k == 1 and r.res is None and (exact or tail):
                 users[r.dst.buf].add(i)
                 writers[r.dst.buf].add(i)
+                if tail:                                  # the fused launch reads the earlier slices of the concat buffer
+                    deps[i] |= {k for k in range(i) if prog.ops[k].dst.buf == r.src.buf and overlap(prog.ops[k].dst.choff, written(prog.ops[k]), r.src.choff, o.dst.choff - r.src.choff)}
     anc = [set() for _ in range(n)]
     for i in range(n):
         for d in deps[i]:

@@ -29,6 +29,54 @@ if sched_log and os.path.exists(sched_log):
             if int(pos) == 0: sched = []
             sched.append(int(op)); launched[int(op)] = on == "1"
     if sched: orders.append(sched)                          # ... and the multi-stream schedule (timed passes)
+# The latency-bound regime runs a STEP schedule ("[step] k: singles i:name ... | group i:name ..." lines of the engine log): the ops
+# of a step are independent, its grouped convs are ONE launch (conv_group_f32).  Reported by its own code path below.
+steps = []
+if sched_log and os.path.exists(sched_log):
+    for l in open(sched_log):
+        if l.startswith("[step] "):
+            head, _, grp = l.partition(" | group")
+            k = int(head.split()[1].rstrip(":"))
+            if k == 0: steps = []
+            singles = [int(t.split(":")[0]) for t in head.split("singles")[1].split()]
+            group = [int(t.split(":")[0]) for t in grp.split()] if grp else []
+            steps.append((singles, group))
+if steps:
+    entries = []                                  # (kernel-name fragment, [ops])
+    for singles, group in steps:
+        entries += [(kind[prog.ops[i].type], [i]) for i in singles]
+        if group: entries.append(("conv_group", group))
+    names = [e[0] for e in entries] + tail
+    passes, i = [], 0
+    while i < len(rows):
+        if i + len(names) <= len(rows) and all(names[j] in rows[i + j]["Kernel_Name"] for j in range(len(names))):
+            e = i + len(names)
+            nms = []
+            while e < len(rows) and "nms_" in rows[e]["Kernel_Name"]:
+                nms.append(rows[e]); e += 1
+            passes.append((rows[i:i + len(names)], sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in nms) / 1e3, len(nms)))
+            i = e
+        else:
+            i += 1
+    print(f"{len(passes)} passes of {len(names) + 1} launches matched ({model}, chunk {chunk}; step schedule, grouped launches = one row)")
+    print(f"{'op(s)':64s} {'kernel':34s} {'grid':>12s} {'lds':>6s} {'vgpr':>5s} {'us':>8s} {'TFLOP/s':>8s}")
+    tot = conv_us = 0.0; conv_launches = 0
+    for j, (frag, ops_l) in enumerate(entries + [("decode_kernel", [])]):
+        d = [(int(p[0][j]["End_Timestamp"]) - int(p[0][j]["Start_Timestamp"])) / 1e3 for p in passes]
+        us = statistics.median(d); tot += us
+        r = passes[0][0][j]
+        kn = r["Kernel_Name"]; kn = kn[:kn.find("(")] if "(" in kn else kn
+        kn = kn.replace("void mi355::", "").replace("mi355::", "")
+        fl = sum(2.0 * c.cout * c.cin * c.k * c.k * (size // c.stride_div) ** 2 * chunk for c in (prog.convs[prog.ops[o].conv] for o in ops_l if prog.ops[o].type in (OP_CONV, OP_STEM)))
+        label = " | ".join(prog.convs[prog.ops[o].conv].name if prog.ops[o].type in (OP_CONV, OP_STEM) else kind[prog.ops[o].type] for o in ops_l) or frag
+        if frag in ("conv", "conv_group"): conv_us += us; conv_launches += 1
+        print(f"{label[:64]:64s} {kn[:34]:34s} {r['Grid_Size_X'] + 'x' + r['Grid_Size_Y']:>12s} {r['LDS_Block_Size']:>6s} {int(r['VGPR_Count'])+int(r['Accum_VGPR_Count']):>5d} {us:8.1f} " + (f"{fl / us / 1e6:8.2f}" if fl else ""))
+    nms_us = statistics.median([p[1] for p in passes]); tot += nms_us
+    print(f"{'nms (' + str(passes[0][2]) + ' launches)':64s} {'':34s} {'':>12s} {'':>6s} {'':>5s} {nms_us:8.1f}")
+    conv_flops = sum(2.0 * c.cout * c.cin * c.k * c.k * (size // c.stride_div) ** 2 * chunk for c in prog.convs if c.cin != 3)
+    print(f"sum of medians: {tot:.1f} us per pass of {chunk} frames -> {chunk / tot * 1e6:.0f} frames/s device-only; {len(names) + passes[0][2]} launches per pass")
+    print(f"conv launches (single convs + grouped launches): {conv_launches} per pass, {conv_us:.1f} us -> {conv_flops / conv_us / 1e6:.2f} TFLOP/s")
+    sys.exit(0)
 # split the trace into passes: a pass is the kernel sequence of one of the orders (ops that are fused away are not launched)
 cands = []
 for o in orders:
