@@ -68,7 +68,7 @@ double latency_factor(const Shape& sh, long blocks, int PT, int CT, int split = 
 // Candidate launch plans for one conv: for every wave arrangement (CT, WC) the best output tile, with every
 // feasible staged-channel count.  Sorted by a static cost model; the engine may time the first few (autotune).
 std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int cin, int ks, int stride, bool have_zero_page, bool half,
-                                  int f2_cin16 = 0) {
+                                  int f2_cin16 = 0, bool need_v4 = false) {
     static const int max_ct = env_int("MI355_MAX_CT", 5);          // tuning knobs (experiments only)
     static const int min_wc = env_int("MI355_MIN_WC", 1);
     static const int small_pt = env_int("MI355_SMALL_PT", 1);      // 0: never offer the 1- / 2-pixel-tile wave shapes
@@ -181,7 +181,11 @@ std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int ci
                 out.push_back(p3);
             }
     }
-    if (ks == 1 && have_zero_page) {   // persistent software-pipelined pointwise kernel (v4); ck in 4-byte units (fp16: 2 channels each)
+    // Latency-bound launches: the pipelined kernel (two barriers per item, a prologue of its own) never won there (10+ us against
+    // 6 us for the streaming kernel on the 20x20 .. 80x80 maps of a single frame) -- and its many shapes crowded the streaming
+    // kernel's best variants out of the candidates the autotuner times (the list is cut at 32): offered only where the conv needs
+    // it (the upsample fused into its read side exists in this kernel alone).
+    if (ks == 1 && have_zero_page && (!latency_bound || need_v4 || half)) {   // persistent software-pipelined pointwise kernel (v4); ck in 4-byte units (fp16: 2 channels each)
         static const int use_v4 = env_int("MI355_CONV_V4", 1);
         const int wps[3] = {1, 2, 4}, cts[4] = {1, 2, 4, 3}, cks[4] = {128, 64, 32, 16};
         for (int PT : (latency_bound && !half) ? std::vector<int>{4, 2, 1} : std::vector<int>{4})
@@ -349,7 +353,7 @@ const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out
             return "conv: lead channels of a fused pointwise stage must be whole 16-channel blocks of an aligned fp32 slice";
     }
     const std::vector<Plan> plans = enumerate_plans(H, W, c.k == 1 ? 1 : c.B, (c.Cout + 15) / 16, half ? (c.Cin + 1) / 2 : c.Cin, c.k,
-                                                    c.stride, c.zeros != nullptr, half, c.f2_cout ? round_up(c.Cout, 16) : 0);
+                                                    c.stride, c.zeros != nullptr, half, c.f2_cout ? round_up(c.Cout, 16) : 0, c.src2 != nullptr);
     if (plans.empty()) return "conv: no launch plan fits in LDS";
     const char* last_err = nullptr;
     for (const Plan& p : plans) {

@@ -757,6 +757,29 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                                h->dbuf_cs[u.dst_buf] / dv, nb, Hl / sd_in, Wl / sd_in, u.src_c / dv, h->stream));
         return MI355_OK;
     };
+    // Short launches (a few frames per pass) are timed IN CONTEXT: a train of 8 x [spacer, candidate], where the spacer is the
+    // launch that precedes the candidate in the net (its producer, as a rule).  A train of one kernel alone flatters it -- its
+    // input lines, its code and its weights are hot in the caches of the CUs that just ran the same thing -- and flatters
+    // persistent / prefetching kernels most: timed that way the autotuner picked the pipelined pointwise kernel (19 us in the
+    // net, 10 in its train) over the streaming one; with MI355_CONV_V4=0 batch 1 ran 7 % faster.  The spacer's own train time
+    // is subtracted for the log; decisions between alternatives (fused or not, grouped or not) time whole sequences.
+    const ConvLaunch* spacer = nullptr;
+    float spacer_ms = -1.f;
+    auto time_train = [&](const std::function<int()>& body, float* ms_out) -> int {
+        float ms = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            HIPCHK(hipEventRecord(h->ev0, h->stream));
+            for (int j = 0; j < 8; ++j) { const int rc = body(); if (rc) return rc; }
+            HIPCHK(hipEventRecord(h->ev1, h->stream));
+            HIPCHK(hipEventSynchronize(h->ev1));
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
+            ms = std::min(ms, t / 8.0f);
+        }
+        *ms_out = ms;
+        return MI355_OK;
+    };
+    auto launch = [&](const ConvLaunch& l) -> int { KCHK(run_conv(l, h->stream)); return MI355_OK; };
     auto time_list = [&](const std::vector<ConvLaunch>& list, const char* name, int* best_k, float* best_ms) -> int {
         // Time launch plans on the real buffers (outputs are overwritten by the next real pass; the accumulation order is
         // plan-independent, so the choice cannot change results).
@@ -775,16 +798,10 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
             if (ms < 0.1f) {
                 // short launches (small batches): a single 5-20 us launch is at the resolution of the event pair, and candidates
                 // differ by fractions of a microsecond -- time trains of 8 back-to-back launches (as they run in the net) instead
-                ms = 1e30f;
-                for (int rep = 0; rep < 3; ++rep) {
-                    HIPCHK(hipEventRecord(h->ev0, h->stream));
-                    for (int j = 0; j < 8; ++j) KCHK(run_conv(list[k], h->stream));
-                    HIPCHK(hipEventRecord(h->ev1, h->stream));
-                    HIPCHK(hipEventSynchronize(h->ev1));
-                    float t = 0.f;
-                    HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
-                    ms = std::min(ms, t / 8.0f);
-                }
+                if (spacer && spacer_ms < 0.f) { const int rc = time_train([&] { return launch(*spacer); }, &spacer_ms); if (rc) return rc; }
+                const int rc = time_train([&] { if (spacer) { const int r = launch(*spacer); if (r) return r; } return launch(list[k]); }, &ms);
+                if (rc) return rc;
+                if (spacer) ms = std::max(ms - spacer_ms, 1e-4f);
             }
             if (ms < *best_ms) { *best_ms = ms; *best_k = (int)k; }
             if (tune_log)
@@ -794,6 +811,7 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
         }
         return MI355_OK;
     };
+    std::vector<ConvLaunch> finals(h->ops.size());
     if (!have && h->autotune) {
         std::vector<char> done(h->ops.size(), 0);
         for (size_t i = 0; i < h->ops.size(); ++i) {
@@ -816,7 +834,14 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                     HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
                     if (rep > 0) msk = std::min(msk, t);
                 }
-                if (msu + msk < ms) chosen[i] = kUpBase + ku;
+                bool separate = msu + msk < ms;
+                if (ms < 0.1f) {                  // short launches: time both sequences as they would run
+                    float ta = 0.f, tb = 0.f;
+                    int r2 = time_train([&] { if (spacer) { const int r = launch(*spacer); if (r) return r; } return launch(cands[i][k]); }, &ta); if (r2) return r2;
+                    r2 = time_train([&] { if (spacer) { const int r = launch(*spacer); if (r) return r; } const int r = run_upsample(ui); if (r) return r; return launch(cands_u[i][ku]); }, &tb); if (r2) return r2;
+                    separate = tb < ta;
+                }
+                if (separate) chosen[i] = kUpBase + ku;
                 if (tune_log) fprintf(stderr, "[tune] %s: upsample on read %.1f us vs upsample kernel %.1f + conv %.1f us -> %s\n", name, ms * 1e3,
                                       msk * 1e3, msu * 1e3, chosen[i] >= kUpBase ? "separate" : "fused");
             }
@@ -825,12 +850,33 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                 const int j = h->fuse2[i];
                 int kf = 0, kj = 0; float msf = 0.f, msj = 0.f;
                 int rc = time_list(cands_f[i], name, &kf, &msf); if (rc) return rc;
-                rc = time_list(cands[j], h->convs[h->ops[j].conv].name, &kj, &msj); if (rc) return rc;
+                const ConvLaunch* outer = spacer; const float outer_ms = spacer_ms;
+                const ConvLaunch first = chosen[i] >= kUpBase ? cands_u[i][chosen[i] - kUpBase] : cands[i][chosen[i]];
+                spacer = &first; spacer_ms = -1.f;                       // the pointwise conv's producer is this conv
+                rc = time_list(cands[j], h->convs[h->ops[j].conv].name, &kj, &msj);
+                spacer = outer; spacer_ms = outer_ms;
+                if (rc) return rc;
                 chosen[j] = kj; done[j] = 1;
-                if (msf < ms + msj) chosen[i] = -(kf + 1);
+                bool fuse = msf < ms + msj;
+                if (ms < 0.1f && chosen[i] < kUpBase) {                   // short launches: time both sequences as they would run
+                    float ta = 0.f, tb = 0.f;
+                    rc = time_train([&] { if (spacer) { const int r = launch(*spacer); if (r) return r; } return launch(cands_f[i][kf]); }, &ta); if (rc) return rc;
+                    rc = time_train([&] { if (spacer) { const int r = launch(*spacer); if (r) return r; } const int r = launch(first); if (r) return r; return launch(cands[j][kj]); }, &tb); if (rc) return rc;
+                    fuse = ta < tb;
+                }
+                if (fuse) chosen[i] = -(kf + 1);
                 if (tune_log) fprintf(stderr, "[tune] %s: fused %.1f us vs separate %.1f + %.1f us -> %s\n", name, msf * 1e3, ms * 1e3, msj * 1e3,
                                       chosen[i] < 0 ? "fused" : "separate");
             }
+            // the launch that will precede the next op in the net becomes the next spacer
+            finals[i] = chosen[i] < 0 ? cands_f[i][-chosen[i] - 1] : chosen[i] >= kUpBase ? cands_u[i][chosen[i] - kUpBase] : cands[i][chosen[i]];
+            spacer = &finals[i];
+            if (h->fuse2[i] >= 0 && chosen[i] >= 0 && done[h->fuse2[i]]) {
+                const int j = h->fuse2[i];
+                finals[j] = cands[j][chosen[j]];
+                spacer = &finals[j];
+            }
+            spacer_ms = -1.f;
         }
         have = true;
         h->plan_source = 3;
@@ -890,7 +936,10 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
         if (!have_groups && have && h->autotune) {
             // decide per step by the stopwatch: the convs whose kernel is on the group kernel's menu, as one grid, against
             // the same convs launched one after the other with their individually best plans
+            int prev_conv = -1, prev_next = -1;         // a conv launched in the previous step (the spacer of this step's timings)
             for (auto& st : h->steps) {
+                prev_conv = prev_next;
+                for (int i : st.singles) if (h->ops[i].type == OP_CONV) { prev_next = i; break; }
                 struct Member { int op, sel; ConvLaunch l; int kind; float t_ind; };
                 std::vector<Member> mem;
                 for (int i : st.singles) {
@@ -924,16 +973,14 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                 for (const Member& m : mem) { ls.push_back(m.l); kinds.push_back(m.kind); t_sum += m.t_ind; }
                 GroupLaunch g{};
                 if (plan_group(ls, kinds, &g) != nullptr) continue;
+                // both forms in context: [the previous step's conv, grouped launch] against [the same conv, the members one by one]
+                const ConvLaunch* gsp = prev_conv >= 0 ? &h->plans[prev_conv] : nullptr;
                 float t_grp = 1e30f;
-                for (int rep = 0; rep < 4; ++rep) {
-                    HIPCHK(hipEventRecord(h->ev0, h->stream));
-                    for (int j = 0; j < 8; ++j) KCHK(run_group(g, h->stream));
-                    HIPCHK(hipEventRecord(h->ev1, h->stream));
-                    HIPCHK(hipEventSynchronize(h->ev1));
-                    float t = 0.f;
-                    HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
-                    if (rep > 0) t_grp = std::min(t_grp, t / 8.0f);
-                }
+                int rcg = time_train([&] { if (gsp) { const int r = launch(*gsp); if (r) return r; } KCHK(run_group(g, h->stream)); return (int)MI355_OK; }, &t_grp);
+                if (rcg) return rcg;
+                rcg = time_train([&] { if (gsp) { const int r = launch(*gsp); if (r) return r; }
+                                       for (const Member& m : mem) { const int r = launch(h->plans[m.op]); if (r) return r; } return (int)MI355_OK; }, &t_sum);
+                if (rcg) return rcg;
                 static int dbg_seq = 0;
                 const char* only = getenv("MI355_GROUP_ONLY");        // debugging: accept only the n-th candidate group
                 const bool dbg_ok = !only || atoi(only) == dbg_seq;
@@ -973,7 +1020,10 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
     if (getenv("MI355_SCHED_LOG"))
         for (size_t k = 0; k < h->steps.size(); ++k) {
             fprintf(stderr, "[step] %zu: singles", k);
-            for (int i : h->steps[k].singles) fprintf(stderr, " %d:%s", i, h->ops[i].type == OP_CONV || h->ops[i].type == OP_STEM ? h->convs[h->ops[i].conv].name : h->ops[i].type == OP_UPSAMPLE ? "upsample" : "sppf_pools");
+            for (int i : h->steps[k].singles) {
+                fprintf(stderr, " %d:%s", i, h->ops[i].type == OP_CONV || h->ops[i].type == OP_STEM ? h->convs[h->ops[i].conv].name : h->ops[i].type == OP_UPSAMPLE ? "upsample" : "sppf_pools");
+                if (h->ops[i].type == OP_CONV) fprintf(stderr, "[v%d,PT%d,CT%d,WP%d%s%s]", h->plans[i].version, h->plans[i].PT, h->plans[i].CT, h->plans[i].WP, h->plans[i].a.w2 ? ",+1x1" : "", h->plans[i].a.up_c ? ",up" : "");
+            }
             if (h->steps[k].group >= 0) {
                 fprintf(stderr, " | group");
                 const GroupLaunch& g = h->groups[h->steps[k].group];
