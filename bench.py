@@ -243,10 +243,8 @@ def cpu_reference(model_name: str, sd, frames_np, size: int, batch: int, budget_
     return rep, want
 
 
-def measure_config(model_name: str, size: int, batch: int, half: bool, steps: int, warmup: int, cpu_budget_s: float = 0.0,
-                   with_cpu: bool = True) -> dict:
-    """One BASELINE configuration on this GPU: frames resident in HBM, rows returned to the host every step; beside it the
-    torch-CPU reference at the same batch and the parity figures of the same frames."""
+def measure_config(model_name: str, size: int, batch: int, half: bool, steps: int, warmup: int, cpu_budget_s: float = 0.0) -> dict:
+    """One BASELINE configuration on this GPU: frames resident in HBM, rows returned to the host every step."""
     import torch
     from cvsd_amd import YOLO
     from cvsd_amd.weights import build_from_state_dict
@@ -271,20 +269,36 @@ def measure_config(model_name: str, size: int, batch: int, half: bool, steps: in
            "roofline": {"achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                         "launches_per_step": launches, "plan_hash": plan["plan_hash"], "plan_source": plan["plan_source"]},
            "activation_bytes": plan["activation_bytes"]}
-    del frames
-    if with_cpu and cpu_budget_s > 0:
-        n_par = min(batch, len(frames_np))
-        if half:
-            out["cpu_baseline"], _ = cpu_reference(model_name, sd, frames_np, size, batch, cpu_budget_s,
-                                                   fp32_note="; fp32 on the CPU (Ultralytics refuses half=True on CPU: there is no fp16 CPU path to time)")
-            out["parity"] = half_parity_report(model_name, sd, frames_np[:n_par], size, model)
-        else:
-            out["cpu_baseline"], want = cpu_reference(model_name, sd, frames_np, size, batch, cpu_budget_s)
-            out["parity"] = parity_report(model, model_name, sd, frames_np[:n_par], size, want=want[:n_par],
-                                          f64_frames=1 if conv_flops_per_frame(model_name, size) > 2e10 else 2)
-    del model
+    del frames, model
     torch.cuda.empty_cache()
     return out
+
+
+def config_cpu_and_parity(out: dict, model_name: str, size: int, batch: int, half: bool, steps: int, warmup: int, cpu_budget_s: float = 0.0) -> None:
+    """Second phase, AFTER every GPU timing of the line: the torch-CPU reference at this config's batch and the parity figures of
+    the same frames (the engine is re-created: its launch plans come from the plan file the first phase wrote).  Kept apart from
+    the GPU timings because the CPU reference's worker threads keep spinning between calls and slow the host side of a
+    latency-bound GPU loop down by 10-20 % (measured at batch 1)."""
+    import torch
+    from cvsd_amd import YOLO
+    from cvsd_amd.weights import build_from_state_dict
+    from tools import synth
+    if cpu_budget_s <= 0:
+        return
+    _, sd = synth.synthetic_checkpoint(model_name, seed=0)
+    model = YOLO(build_from_state_dict(model_name, sd), device=torch.cuda.current_device(), batch_chunk=batch, half=half)
+    _, frames_np = make_frames(min(batch, N_BASE_FRAMES), size, seed=2000 + batch)
+    n_par = min(batch, len(frames_np))
+    if half:
+        out["cpu_baseline"], _ = cpu_reference(model_name, sd, frames_np, size, batch, cpu_budget_s,
+                                               fp32_note="; fp32 on the CPU (Ultralytics refuses half=True on CPU: there is no fp16 CPU path to time)")
+        out["parity"] = half_parity_report(model_name, sd, frames_np[:n_par], size, model)
+    else:
+        out["cpu_baseline"], want = cpu_reference(model_name, sd, frames_np, size, batch, cpu_budget_s)
+        out["parity"] = parity_report(model, model_name, sd, frames_np[:n_par], size, want=want[:n_par],
+                                      f64_frames=1 if conv_flops_per_frame(model_name, size) > 2e10 else 2)
+    del model
+    torch.cuda.empty_cache()
 
 
 def launch_ranks(n: int, argv: list) -> int:
@@ -514,7 +528,8 @@ def main() -> None:
     plan = model.plan_info()
     line["roofline"]["plan_hash"], line["roofline"]["plan_source"] = plan["plan_hash"], plan["plan_source"]
     line["config"]["activation_bytes_per_gpu"] = plan["activation_bytes"]
-    if world == 1 and not args.no_cpu_baseline and not args.half:
+    want_cpu = world == 1 and not args.no_cpu_baseline and not args.half
+    if want_cpu and not (world == 1 and headline_default and not args.no_configs):
         line["cpu_baseline"] = cpu_baseline(args, sd, frames_np, model)
     if world == 1 and headline_default and not args.no_configs:
         # the headline workload fed from PINNED host memory, 128-frame chunks (measured best of 32 / 64 / 128 / 256: 8,455 / 9,043 /
@@ -525,16 +540,25 @@ def main() -> None:
         m2 = YOLO(blob, device=local_rank, batch_chunk=128)
         for _ in range(2):
             m2._infer_rows(host, 0.25, 0.7, None, 300, args.size)
-        t0 = time.perf_counter()
-        HS = 5
-        for _ in range(HS):
-            m2._infer_rows(host, 0.25, 0.7, None, 300, args.size)
-        torch.cuda.synchronize()
-        line["host_fed_value"] = {"value": round(B * HS / (time.perf_counter() - t0), 1), "unit": "frames/s",
+        HS, rates = 3, []
+        for _ in range(3):                                   # median of three timed groups of three steps (the PCIe-fed rate varies +-5 % run to run)
+            t0 = time.perf_counter()
+            for _ in range(HS):
+                m2._infer_rows(host, 0.25, 0.7, None, 300, args.size)
+            torch.cuda.synchronize()
+            rates.append(B * HS / (time.perf_counter() - t0))
+        line["host_fed_value"] = {"value": round(sorted(rates)[1], 1), "unit": "frames/s", "min": round(min(rates), 1), "max": round(max(rates), 1),
                                   "what": "same workload, frames in pinned host memory, engine chunk 128 (H2D of chunk k+1 overlaps chunk k)"}
         del m2, host, frames
         torch.cuda.empty_cache()
-        line["configs"] = [measure_config(*c, with_cpu=not args.no_cpu_baseline) for c in EXTRA_CONFIGS]
+        line["configs"] = [measure_config(*c) for c in EXTRA_CONFIGS]                      # every GPU timing first ...
+        if want_cpu:                                                                        # ... then the CPU reference runs and the parity figures
+            m3 = YOLO(blob, device=local_rank, batch_chunk=args.chunk)
+            line["cpu_baseline"] = cpu_baseline(args, sd, frames_np, m3)
+            del m3
+            torch.cuda.empty_cache()
+            for out, c in zip(line["configs"], EXTRA_CONFIGS):
+                config_cpu_and_parity(out, *c)
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
