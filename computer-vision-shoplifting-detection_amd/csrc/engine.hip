@@ -567,6 +567,25 @@ static void save_plan_choices(const mi355_yolo* h, int nb, int Hl, int Wl, const
     if (std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());   // atomic: ranks may race
 }
 
+// event bookkeeping for per-kind timing
+enum Kind { K_LETTERBOX, K_STEM, K_CONV, K_POOL, K_UPSAMPLE, K_DECODE, K_NMS, K_COUNT };
+struct Prof {
+    mi355_yolo* h; size_t used = 0; std::vector<std::pair<int, size_t>> spans;
+    int begin(int kind) {
+        if (!h->profiling) return 0;
+        if (used + 2 > h->pev.size()) { for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return -1; h->pev.push_back(e); } }
+        spans.push_back({kind, used});
+        return hipEventRecord(h->pev[used], h->stream) == hipSuccess ? 0 : -1;
+    }
+    int end() {
+        if (!h->profiling) return 0;
+        const int r = hipEventRecord(h->pev[used + 1], h->stream) == hipSuccess ? 0 : -1;
+        used += 2; return r;
+    }
+};
+
+static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, const Geometry& g, bool full_pred);
+
 // Liveness-based placement of the activation buffers in ONE arena (host arithmetic only).  Fills h->dbuf_cs / dbuf_es.
 static void plan_memory(mi355_yolo* h, int nb, int Hl, int Wl, std::vector<size_t>* off_out, std::vector<size_t>* bytes_out,
                         size_t* arena_out, size_t* plain_out) {
@@ -747,6 +766,9 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
             fp = fnv1a(fp, &prop.multiProcessorCount, sizeof(int));
         }
         for (size_t i = 0; i < h->ops.size(); ++i) { fp = cand_fingerprint(fp, cands[i]); fp = cand_fingerprint(fp, cands_f[i]); fp = cand_fingerprint(fp, cands_u[i]); }
+        // the scheduling regime the choices were made for (a file written with grouped launches off must not pin "no groups")
+        const int regime[3] = {h->use_groups, h->group_max_batch, h->streams_min_batch};
+        fp = fnv1a(fp, regime, sizeof(regime));
     }
     h->plan_source = have ? 1 : 0;          // 1 = this process's memory
     if (!have && h->autotune) { have = load_plan_choices(h, nb, Hl, Wl, n_cands, fp, &chosen, &gsel); if (have) { h->plan_source = 2; have_groups = true; } }
@@ -812,6 +834,10 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
         return MI355_OK;
     };
     std::vector<ConvLaunch> finals(h->ops.size());
+    // both forms of every binary decision (index into `chosen`'s encoding; -9999 = the form does not exist), for the pass-level check below
+    constexpr int kNone = -9999;
+    std::vector<int> alt_fused(h->ops.size(), kNone), alt_sep(h->ops.size(), kNone), alt_read(h->ops.size(), kNone), alt_up(h->ops.size(), kNone);
+    const std::vector<char> fused_away_base(h->fused_away.begin(), h->fused_away.end());     // as pass 1 left it (upsample read through the conv where possible)
     if (!have && h->autotune) {
         std::vector<char> done(h->ops.size(), 0);
         for (size_t i = 0; i < h->ops.size(); ++i) {
@@ -841,6 +867,7 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                     r2 = time_train([&] { if (spacer) { const int r = launch(*spacer); if (r) return r; } const int r = run_upsample(ui); if (r) return r; return launch(cands_u[i][ku]); }, &tb); if (r2) return r2;
                     separate = tb < ta;
                 }
+                alt_read[i] = k; alt_up[i] = kUpBase + ku;
                 if (separate) chosen[i] = kUpBase + ku;
                 if (tune_log) fprintf(stderr, "[tune] %s: upsample on read %.1f us vs upsample kernel %.1f + conv %.1f us -> %s\n", name, ms * 1e3,
                                       msk * 1e3, msu * 1e3, chosen[i] >= kUpBase ? "separate" : "fused");
@@ -864,6 +891,7 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                     rc = time_train([&] { if (spacer) { const int r = launch(*spacer); if (r) return r; } const int r = launch(first); if (r) return r; return launch(cands[j][kj]); }, &tb); if (rc) return rc;
                     fuse = ta < tb;
                 }
+                alt_sep[i] = chosen[i]; alt_fused[i] = -(kf + 1);
                 if (fuse) chosen[i] = -(kf + 1);
                 if (tune_log) fprintf(stderr, "[tune] %s: fused %.1f us vs separate %.1f + %.1f us -> %s\n", name, msf * 1e3, ms * 1e3, msj * 1e3,
                                       chosen[i] < 0 ? "fused" : "separate");
@@ -881,7 +909,9 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
         have = true;
         h->plan_source = 3;
     }
-    if (have) {
+    auto apply_plans = [&]() {                   // `chosen` -> the launch plan of every conv, which ops run inside another's launch
+        std::fill(h->skip_op.begin(), h->skip_op.end(), 0);
+        std::copy(fused_away_base.begin(), fused_away_base.end(), h->fused_away.begin());
         for (size_t i = 0; i < h->ops.size(); ++i) {
             if (h->ops[i].type != OP_CONV) continue;
             if (chosen[i] < 0 && (size_t)(-chosen[i] - 1) < cands_f[i].size()) {
@@ -892,9 +922,12 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                 h->fused_away[h->fuse_up[i]] = 0;       // the upsample kernel runs; this conv reads its output
             } else if (chosen[i] >= 0 && (size_t)chosen[i] < cands[i].size()) {
                 h->plans[i] = cands[i][chosen[i]];
+            } else {
+                h->plans[i] = cands[i][0];
             }
         }
-    }
+    };
+    if (have) apply_plans();
     // ---- grouped launches of the single-stream regime: list-schedule the launched ops into steps, then decide per step ----
     h->groups.clear(); h->steps.clear();
     h->group_sel.assign(n_ops, -1);
@@ -903,7 +936,9 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
     auto list_of = [&](int i) -> const std::vector<ConvLaunch>& {      // the candidate list op i's current plan was taken from
         return (h->fuse2[i] >= 0 && h->skip_op[h->fuse2[i]]) ? cands_f[i] : chosen[i] >= kUpBase ? cands_u[i] : cands[i];
     };
-    if (stepwise) {
+    auto build_steps = [&]() -> int {
+        h->steps.clear(); h->groups.clear();
+        std::fill(h->group_sel.begin(), h->group_sel.end(), -1);
         // avail[i] = step after which op i's output exists; an op is ready when all its producers are available
         const int n = (int)n_ops;
         std::vector<int> avail(n, -1), producer_of(n, -1);
@@ -933,7 +968,10 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
             for (int i : now) { placed[i] = 1; avail[i] = step; --left; st.singles.push_back(i); }
             h->steps.push_back(st);
         }
-        if (!have_groups && have && h->autotune) {
+        return MI355_OK;
+    };
+    auto tune_groups = [&]() -> int {
+        {
             // decide per step by the stopwatch: the convs whose kernel is on the group kernel's menu, as one grid, against
             // the same convs launched one after the other with their individually best plans
             int prev_conv = -1, prev_next = -1;         // a conv launched in the previous step (the spacer of this step's timings)
@@ -994,9 +1032,11 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
                 if (t_grp < 0.97f * t_sum && h->use_groups != 2 && dbg_ok)         // MI355_GROUPS=2: step order without grouped launches (debugging)
                     for (const Member& m : mem) gsel[m.op] = m.sel;
             }
-            have_groups = true;
         }
-        // materialise the decisions: members with a selection leave the step's single launches and form its group
+        return MI355_OK;
+    };
+    auto materialise_groups = [&]() {
+        // members with a selection leave the step's single launches and form its group
         for (auto& st : h->steps) {
             std::vector<int> members, singles;
             for (int i : st.singles) {
@@ -1016,6 +1056,89 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
             st.singles = singles; st.group = (int)h->groups.size();
             h->groups.push_back(g);
         }
+    };
+    // One whole pass of the net (stem .. decode) with the current decisions, in the order and with the launches the product runs:
+    // the yardstick for decisions whose effect depends on what runs before and after (a fused launch, a grouped launch).
+    auto time_pass = [&](float* ms_out) -> int {
+        const Geometry g = make_geometry(Hl, Wl, std::max(Hl, Wl));
+        Prof pf{h};
+        const bool was = h->profiling; h->profiling = false;
+        const int cur = h->cur_nb; h->cur_nb = nb;
+        float best = 1e30f;
+        int rc = MI355_OK;
+        for (int rep = 0; rep < 4 && !rc; ++rep) {
+            if (hipEventRecord(h->ev0, h->stream) != hipSuccess) { rc = fail(MI355_EHIP, "event"); break; }
+            for (int j = 0; j < 24 && !rc; ++j) rc = launch_net(h, pf, h->lbox, nb, g, false);
+            if (rc) break;
+            if (hipEventRecord(h->ev1, h->stream) != hipSuccess || hipEventSynchronize(h->ev1) != hipSuccess) { rc = fail(MI355_EHIP, "event"); break; }
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, h->ev0, h->ev1);
+            if (rep > 0) best = std::min(best, t / 24.0f);
+        }
+        h->profiling = was; h->cur_nb = cur;
+        *ms_out = best;
+        return rc;
+    };
+    if (stepwise) {
+        int rc = build_steps(); if (rc) return rc;
+        const bool fresh = !have_groups && have && h->autotune;
+        static const int pass_tune = getenv("MI355_PASS_TUNE") ? atoi(getenv("MI355_PASS_TUNE")) : 1;
+        if (fresh && h->plan_source == 3 && pass_tune) {
+            // Pass-level check of the binary decisions (fp32, latency-bound regime).  The per-op stopwatch compares a fused launch
+            // with its two halves in a train of their own; what the choice does to the PASS -- caches, the launch behind it, the
+            // steps it merges or splits -- shows only there.  Greedy: flip one decision, time whole passes, keep what is faster.
+            float best = 0.f;
+            rc = time_pass(&best); if (rc) return rc;
+            auto try_flip = [&](size_t i, int a, int b, const char* what) -> int {
+                if (a == kNone || b == kNone) return MI355_OK;
+                const int old = chosen[i], alt = old == a ? b : a;
+                chosen[i] = alt;
+                apply_plans();
+                int r = build_steps(); if (r) return r;
+                float t = 0.f;
+                r = time_pass(&t); if (r) return r;
+                const bool keep = t < 0.997f * best;
+                if (tune_log) fprintf(stderr, "[tune] pass check %s %s: %.1f us -> %.1f us per pass: %s\n", h->convs[h->ops[i].conv].name, what, best * 1e3, t * 1e3,
+                                      keep ? "flipped" : "kept");
+                if (keep) best = t; else { chosen[i] = old; apply_plans(); r = build_steps(); if (r) return r; }
+                return MI355_OK;
+            };
+            for (size_t i = 0; i < n_ops; ++i) {
+                rc = try_flip(i, alt_fused[i], alt_sep[i], "fused <-> separate"); if (rc) return rc;
+                if (chosen[i] >= 0) { rc = try_flip(i, alt_read[i], alt_up[i], "upsample on read <-> kernel"); if (rc) return rc; }
+            }
+        }
+        if (fresh) {
+            rc = tune_groups(); if (rc) return rc;
+            have_groups = true;
+            if (h->plan_source == 3 && pass_tune) {
+                // the same check for every grouped launch the per-step stopwatch accepted
+                materialise_groups();
+                std::vector<std::vector<std::pair<int, int>>> accepted;          // per group: (op, selected plan)
+                for (const auto& st : h->steps)
+                    if (st.group >= 0) {
+                        std::vector<std::pair<int, int>> mem;
+                        const GroupLaunch& g = h->groups[st.group];
+                        for (int m = 0; m < g.n_members; ++m) mem.push_back({g.op[m], gsel[g.op[m]]});
+                        accepted.push_back(mem);
+                    }
+                float best = 0.f;
+                rc = time_pass(&best); if (rc) return rc;
+                for (const auto& mem : accepted) {
+                    for (const auto& sv : mem) gsel[sv.first] = -1;
+                    rc = build_steps(); if (rc) return rc;
+                    materialise_groups();
+                    float t = 0.f;
+                    rc = time_pass(&t); if (rc) return rc;
+                    const bool drop = t < 0.997f * best;
+                    if (tune_log) fprintf(stderr, "[tune] pass check group with %s: %.1f us with -> %.1f us without: %s\n", h->convs[h->ops[mem[0].first].conv].name,
+                                          best * 1e3, t * 1e3, drop ? "dropped" : "kept");
+                    if (drop) best = t; else for (const auto& sv : mem) gsel[sv.first] = sv.second;
+                }
+                rc = build_steps(); if (rc) return rc;
+            }
+        }
+        materialise_groups();
     }
     if (getenv("MI355_SCHED_LOG"))
         for (size_t k = 0; k < h->steps.size(); ++k) {
@@ -1055,25 +1178,6 @@ static int ensure_shape(mi355_yolo* h, int nb, int Hl, int Wl) {
     }
     return MI355_OK;
 }
-
-// event bookkeeping for per-kind timing
-enum Kind { K_LETTERBOX, K_STEM, K_CONV, K_POOL, K_UPSAMPLE, K_DECODE, K_NMS, K_COUNT };
-struct Prof {
-    mi355_yolo* h; size_t used = 0; std::vector<std::pair<int, size_t>> spans;
-    int begin(int kind) {
-        if (!h->profiling) return 0;
-        if (used + 2 > h->pev.size()) { for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return -1; h->pev.push_back(e); } }
-        spans.push_back({kind, used});
-        return hipEventRecord(h->pev[used], h->stream) == hipSuccess ? 0 : -1;
-    }
-    int end() {
-        if (!h->profiling) return 0;
-        const int r = hipEventRecord(h->pev[used + 1], h->stream) == hipSuccess ? 0 : -1;
-        used += 2; return r;
-    }
-};
-
-static int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, const Geometry& g, bool full_pred);
 
 // run the net (+decode) on nb frames that sit in `frames_dev` (original size h0 x w0, dense).
 // Launch-bound regime: the stem..decode sequence (60-100 launches) is captured once per chunk size into a hipGraph
