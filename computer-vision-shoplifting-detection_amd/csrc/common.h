@@ -84,6 +84,7 @@ struct ConvKArgs {
     int n_tiles_total;         // B * tiles_x * tiles_y (persistent kernels walk tiles blockIdx.x, + gridDim.x, ...)
     FastDiv fd_tx, fd_ty, fd_gy;   // conv_igemm_f32: scalar division by tiles_x, tiles_y, gridDim.y
     int img_src, img_dst, img_res; // conv_igemm_f32: elements per image of the source / destination / residual slices' buffers (H * W * cs)
+    int THin, st_rpi, st_nseg; float inv_row_slots;   // conv_igemm_f16 staging: halo rows, rows / row segments per 256-thread pass, 1 / (16-byte slots per halo row)
 };
 // A planned launch: kernel instance, grid, LDS bytes and kernel arguments.  Planning (tile / wave-arrangement
 // search) is done once per (op, shape) by the engine; run_conv only enqueues.
@@ -172,7 +173,8 @@ struct NmsArgs {
     // scale-back (A.6); identity when scale_back == 0
     int scale_back; float gain; float pad_x, pad_y, kpad_x, kpad_y; float orig_w, orig_h;
     void* out_rows;                            // device mi355_det [B][max_det]
-    int* out_counts;                           // device [B]
+    int* out_counts;                           // device [B] (+ [B, 3B): scratch of the sort kernels)
+    int* host_counts = nullptr;                // optional: pinned host [B], written by the greedy kernel beside out_counts
 };
 const char* launch_nms(const NmsArgs& a, hipStream_t st);
 

@@ -102,6 +102,220 @@ __device__ __forceinline__ void store_tiles_f16(const ConvKArgs& a, f32x4 (&acc)
         }
 }
 
+// ---- round 3: the same kernel on a vector-instruction diet --------------------------------------------------------------
+// One f16 MFMA is 16 cycles, so at K = 432 .. 1728 a wave's whole K loop is 3.5k .. 14k cycles -- and the staging loop and the
+// epilogue used to cost as much again in address arithmetic (PMC round 2: 3.0 - 7.5 vector instructions per MFMA, matrix pipe
+// busy 20 - 42 %).  MI355_F16_DIET=1 (default): the halo tile is staged row by row through a buffer descriptor over this
+// image (per load: one multiply-add, two compares, one select; lanes outside the image read zeros because their offset lies
+// past num_records -- no zero page, no 64-bit pointer per load), the tile decomposition runs on the scalar unit, and the
+// epilogue stores / residual loads go through descriptors with one 32-bit offset per pixel tile, branch-free.
+#ifndef MI355_F16_DIET
+#define MI355_F16_DIET 1
+#endif
+constexpr unsigned kOOB = 0x80000000u;       // byte offset past any descriptor's num_records (planner: images stay below 2^31 bytes)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// SiLU of two values: the multiplies and the add as packed fp32 instructions, two transcendentals each
+__device__ __forceinline__ f32x2 fast_silu2(f32x2 x) {
+    const f32x2 t = x * (f32x2){-1.44269504088896341f, -1.44269504088896341f};
+    f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    e = e + (f32x2){1.0f, 1.0f};
+    const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    return x * r;
+}
+__device__ __forceinline__ f32x4 bias_act4(f32x4 v, const f32x4& bias, int act) {
+    v += bias;
+    if (act) {
+        const f32x2 lo = fast_silu2((f32x2){v[0], v[1]}), hi = fast_silu2((f32x2){v[2], v[3]});
+        v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
+    }
+    return v;
+}
+
+// Destination of an epilogue: one image of the destination (and residual) slice behind buffer descriptors.
+struct OutF16 {
+    __amdgpu_buffer_rsrc_t drs, rrs;
+    int dst_cs, res_cs, Cout, act, out_f32; bool has_res;
+    const float* dst; const float* res;      // image bases (ragged cout tiles take the pointer path)
+};
+__device__ __forceinline__ OutF16 make_out_f16(const float* dst, int dst_cs, int img_dst, const float* res, int res_cs, int img_res, int b,
+                                               int Cout, int act, int out_f32) {
+    OutF16 o;
+    const unsigned esz = out_f32 ? 4u : 2u;
+    const char* db = (const char*)dst + (size_t)b * (size_t)img_dst * esz;
+    const char* rb = res ? (const char*)res + (size_t)b * (size_t)img_res * esz : db;
+    o.drs = __builtin_amdgcn_make_buffer_rsrc((void*)db, 0, (int)((unsigned)img_dst * esz), 0x00020000);
+    o.rrs = __builtin_amdgcn_make_buffer_rsrc((void*)rb, 0, res ? (int)((unsigned)img_res * esz) : 0, 0x00020000);
+    o.dst_cs = dst_cs; o.res_cs = res_cs; o.Cout = Cout; o.act = act; o.out_f32 = out_f32; o.has_res = res != nullptr;
+    o.dst = (const float*)db; o.res = (const float*)rb;
+    return o;
+}
+
+// pix[pt] = pixel index inside the image (row-major), or -1 for lanes whose pixel lies outside the tile / image.
+template <int PT, int CT>
+__device__ __forceinline__ void store_tiles_f16_v2(const OutF16& o, f32x4 (&acc)[CT][PT], const f32x4 (&bias4)[CT], int lane, int ct0,
+                                                   const int (&pix)[PT]) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const bool pairs = conv_f16_pairs(o.Cout);
+    const unsigned g = (unsigned)lane >> 4;
+    const int n_full = o.Cout >> 4;                       // cout tiles that are complete
+    // last tile of a Cout that is not a multiple of 16 (the 51-channel keypoint branch, one-class models): element stores through
+    // the same descriptors, channels beyond Cout dropped by the offset marker.  c = first cout of this lane's four.
+    auto ragged = [&](f32x4 accv, const f32x4& bias, int c, unsigned dvo, unsigned rvo, int so) {
+        const f32x4 v = bias_act4(accv, bias, o.act);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = c + i < o.Cout;
+            if (o.out_f32) {
+                float r = v[i];
+                if (o.has_res) r += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(o.rrs, (int)(in ? rvo + 4u * i : kOOB), so, 0));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), o.drs, (int)(in ? dvo + 4u * i : kOOB), so, 0);
+            } else {
+                float r = v[i];
+                if (o.has_res) r += (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(o.rrs, (int)(in ? rvo + 2u * i : kOOB), so, 0));
+                const _Float16 h = (_Float16)r;
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), o.drs, (int)(in ? dvo + 2u * i : kOOB), so, 0);
+            }
+        }
+    };
+    if (o.out_f32) {
+        // fp32 destination (the head's final convs): tile t holds couts 16 t + 4 g (bytes 64 t + 16 g) or, in the paired row
+        // order (Cout % 32 == 0), 32 (t >> 1) + 8 g + 4 (t & 1)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const unsigned lane_b = pairs ? g * 32u : g * 16u;
+            const unsigned dvo = pix[pt] >= 0 ? (unsigned)__mul24(pix[pt], o.dst_cs) * 4u + lane_b : kOOB;
+            const unsigned rvo = pix[pt] >= 0 ? (unsigned)__mul24(pix[pt], o.res_cs) * 4u + lane_b : kOOB;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int t = ct0 + ct;                                   // wave-uniform
+                if (t * 16 >= o.Cout) continue;
+                const int so = pairs ? (t >> 1) * 128 + (t & 1) * 16 : t * 64;
+                if (t >= n_full) { ragged(acc[ct][pt], bias4[ct], t * 16 + 4 * (int)g, dvo, rvo, so); continue; }
+                f32x4 v = bias_act4(acc[ct][pt], bias4[ct], o.act);
+                if (o.has_res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(o.rrs, (int)rvo, so, 0));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o.drs, (int)dvo, so, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one pixel tile at a time: the accumulators leave their registers tile by tile
+        }
+        return;
+    }
+    if (pairs && (CT % 2 == 0)) {
+        // ct0 is even: tiles (ct, ct + 1) are a pair -> 8 consecutive couts per lane, one 16-byte fp16 store; pair j at byte 64 j
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const unsigned dvo = pix[pt] >= 0 ? (unsigned)__mul24(pix[pt], o.dst_cs) * 2u + g * 16u : kOOB;
+            const unsigned rvo = pix[pt] >= 0 ? (unsigned)__mul24(pix[pt], o.res_cs) * 2u + g * 16u : kOOB;
+#pragma unroll
+            for (int ct = 0; ct < CT; ct += 2) {
+                const int t = ct0 + ct;
+                if (t * 16 >= o.Cout) continue;                           // pairs: Cout % 32 == 0, so a pair is whole or absent
+                const f32x4 v0 = bias_act4(acc[ct][pt], bias4[ct], o.act), v1 = bias_act4(acc[ct + 1][pt], bias4[ct + 1], o.act);
+                f32x4 w0 = v0, w1 = v1;
+                if (o.has_res) {
+                    const f16x8 rv = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(o.rrs, (int)rvo, (t >> 1) * 64, 0));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { w0[i] += (float)rv[i]; w1[i] += (float)rv[4 + i]; }
+                }
+                f16x8 h;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { h[i] = (_Float16)w0[i]; h[4 + i] = (_Float16)w1[i]; }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), o.drs, (int)dvo, (t >> 1) * 64, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
+    // single tiles, 8-byte fp16 stores: tile t starts at cout 16 t (lane group at + 4 g), or -- paired layout, odd CT -- at
+    // 32 (t >> 1) + 4 (t & 1) (lane group at + 8 g)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const unsigned lane_b = pairs ? g * 16u : g * 8u;
+        const unsigned dvo = pix[pt] >= 0 ? (unsigned)__mul24(pix[pt], o.dst_cs) * 2u + lane_b : kOOB;
+        const unsigned rvo = pix[pt] >= 0 ? (unsigned)__mul24(pix[pt], o.res_cs) * 2u + lane_b : kOOB;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int t = ct0 + ct;
+            if (t * 16 >= o.Cout) continue;
+            const int so = pairs ? (t >> 1) * 64 + (t & 1) * 8 : t * 32;   // bytes, wave-uniform
+            if (t >= n_full) { ragged(acc[ct][pt], bias4[ct], t * 16 + 4 * (int)g, dvo, rvo, so); continue; }
+            f32x4 v = bias_act4(acc[ct][pt], bias4[ct], o.act);
+            if (o.has_res) {
+                const f16x4 rv = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(o.rrs, (int)rvo, so, 0));
+                v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
+            }
+            f16x4 h;
+            h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), o.drs, (int)dvo, so, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Stage the halo tile (3x3) or the pixel tile (1x1) of channels [c0, c0 + ck) into LDS as [pixel][ldp halfs].
+// 3x3: 256 threads cover `st_rpi` whole rows of 16-byte slots per pass (or one row in `st_nseg` segments when a row has more
+// than 256 slots); a thread keeps its column for all rows, so everything but the row term of its address is computed once.
+// 1x1: a pass covers 256 >> sh pixels; a thread keeps its 8-channel slot and walks pixels at a constant byte stride.
+template <int KS>
+__device__ __forceinline__ void stage_tile_f16(const ConvKArgs& a, _Float16* lds_h, const __amdgpu_buffer_rsrc_t srs, int tid, int iy0, int ix0, int c0) {
+    const int sh = a.ck4_shift, smask = (1 << sh) - 1;
+    if constexpr (KS == 1) {
+        const int pps = 256 >> sh;                                   // pixels per pass
+        const int pix0 = tid >> sh, q = tid & smask;
+        const bool okc = c0 + 8 * q < a.cin4;
+        const unsigned vo0 = (unsigned)(__mul24(ix0 + pix0, a.src_cs) + 8 * q) * 2u;
+        const unsigned vstep = (unsigned)__mul24(pps, a.src_cs) * 2u;
+        const int l0 = __mul24(pix0, a.ldp) + 8 * q, lstep = __mul24(pps, a.ldp);
+        const int left = min(a.npix_in, a.Win - ix0);                // pixels of this tile that exist
+        const int npass = (a.npix_in + pps - 1) >> (8 - sh);
+        for (int p0 = 0; p0 < npass; p0 += 8) {
+            f16x8 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int pix = pix0 + (p0 + u) * pps;
+                const unsigned vo = (okc && pix < left) ? vo0 + (unsigned)(p0 + u) * vstep : kOOB;
+                v[u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(srs, (int)vo, c0 * 2, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int pix = pix0 + (p0 + u) * pps;
+                if (pix < a.npix_in) *(f16x8*)(lds_h + l0 + (p0 + u) * lstep) = v[u];
+            }
+        }
+    } else {
+        const int row_slots = a.TWin << sh;
+        const int rpi = a.st_rpi;
+        const unsigned rowbytes = (unsigned)__mul24(a.Win, a.src_cs) * 2u;
+        const int lrow = __mul24(a.TWin, a.ldp);
+        for (int seg = 0; seg < a.st_nseg; ++seg) {
+            int r_in = 0, col = seg * 256 + tid;
+            if (rpi > 1) { r_in = (int)(((float)tid + 0.5f) * a.inv_row_slots); col = tid - __mul24(r_in, row_slots); }
+            const bool colok = col < row_slots && r_in < rpi;
+            const int ix = col >> sh, q = col & smask;
+            const int gx = ix0 + ix;
+            const bool xok = colok && (unsigned)gx < (unsigned)a.Win && c0 + 8 * q < a.cin4;
+            const unsigned vbase = (unsigned)(__mul24(gx, a.src_cs) + 8 * q) * 2u;
+            const int lbase = __mul24(__mul24(r_in, a.TWin) + ix, a.ldp) + 8 * q;
+            for (int row0 = 0; row0 < a.THin; row0 += 8 * rpi) {
+                f16x8 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = row0 + u * rpi + r_in, gy = iy0 + row;
+                    const bool ok = xok && row < a.THin && (unsigned)gy < (unsigned)a.Hin;
+                    const unsigned vo = ok ? vbase + __umul24((unsigned)gy, rowbytes) : kOOB;
+                    v[u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(srs, (int)vo, c0 * 2, 0));
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = row0 + u * rpi + r_in;
+                    if (colok && row < a.THin) *(f16x8*)(lds_h + lbase + __mul24(row0 + u * rpi, lrow)) = v[u];
+                }
+            }
+        }
+    }
+}
+
 // Block = 256 threads = 4 waves, WP along pixels x WC along couts; a wave owns PT pixel tiles x CT cout tiles of 16x16.
 // The halo tile is staged through LDS in chunks of a.ck channels (a.ck halfs, pixel stride a.ldp = ck + 8 halfs).
 // F2 (3x3 convs): a pointwise conv fused behind this one.  The block must cover ALL couts of the 3x3 conv (grid.y == 1); its
@@ -120,10 +334,17 @@ __global__ __launch_bounds__(256, (PT == 8 ? (CT <= 3 ? 3 : 2) : 1)) void conv_i
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, 0x7fffffff, 0x00020000);
     const int wp = wave % WP, wc = wave / WP;
     int t, cgrp0;
+#if MI355_F16_DIET
+    // tile decomposition on the scalar unit (as conv_igemm_f32)
+    xcd_work_item(t, cgrp0, FastDiv{a.fd_gy.ml, a.fd_gy.mh}, MI355_BLOCK_ID());
+    const int tq = (int)fastdiv((unsigned)t, FastDiv{a.fd_tx.ml, a.fd_tx.mh}), tx = t - tq * a.tiles_x;
+    const int b = (int)fastdiv((unsigned)tq, FastDiv{a.fd_ty.ml, a.fd_ty.mh}), ty = tq - b * a.tiles_y;
+#else
     xcd_work_item(t, cgrp0);
     const int tx = t % a.tiles_x; t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     const int b = t / a.tiles_y;
+#endif
     const int oy0 = ty * a.TH, ox0 = tx * a.TW;
     const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
     const int ct0 = (cgrp0 * WC + wc) * CT;
@@ -134,9 +355,13 @@ __global__ __launch_bounds__(256, (PT == 8 ? (CT <= 3 ? 3 : 2) : 1)) void conv_i
         const int p = (wp * PT + pt) * 16 + (lane & 15);
         const int pp = p < npix ? p : 0;
         const int ly = (int)(((float)pp + 0.5f) * a.inv_TW);
-        const int lx = pp - ly * a.TW;
-        xoff[pt] = ((ly * STRIDE) * a.TWin + lx * STRIDE) * a.ldp + (lane >> 4) * 8;
+        const int lx = pp - __mul24(ly, a.TW);
+        xoff[pt] = __mul24(__mul24(ly * STRIDE, a.TWin) + lx * STRIDE, a.ldp) + (lane >> 4) * 8;
     }
+#if MI355_F16_DIET
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)a.src + (size_t)b * (size_t)a.img_src), 0,
+                                                                         (int)((unsigned)a.img_src * 2u), 0x00020000);
+#endif
     f32x4 acc[CT][PT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -163,8 +388,13 @@ __global__ __launch_bounds__(256, (PT == 8 ? (CT <= 3 ? 3 : 2) : 1)) void conv_i
 #endif
     for (int c0 = 0; c0 < a.Cin; c0 += a.ck) {
         if (c0) __syncthreads();
+#if MI355_F16_DIET
+        if (!(exp_flags & 1)) stage_tile_f16<KS>(a, lds_h, srs, tid, iy0, ix0, c0);
+        for (int base = 0; base < 0; base += 8 * 256) {
+#else
         // stage the halo tile, channels [c0, c0+ck): 8 loads per thread in flight, zero page outside the image / beyond Cin
         for (int base = 0; base < ((exp_flags & 1) ? 0 : total_v); base += 8 * 256) {
+#endif
             f16x8 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -351,14 +581,16 @@ __global__ __launch_bounds__(256, (PT == 8 ? (CT <= 3 ? 3 : 2) : 1)) void conv_i
     }
     // epilogue operands are derived here, not before the K loop: 3 registers per pixel tile and 4 per cout tile less to carry
     size_t po[PT]; bool ok[PT];
+    int pixi[PT];                                   // pixel index inside image b, -1 = no store (MI355_F16_DIET)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int p = (wp * PT + pt) * 16 + (lane & 15);
         const int pp = p < npix ? p : 0;
         const int ly = (int)(((float)pp + 0.5f) * a.inv_TW);
-        const int lx = pp - ly * a.TW;
+        const int lx = pp - __mul24(ly, a.TW);
         const int oy = oy0 + ly, ox = ox0 + lx;
         ok[pt] = (p < npix) && (oy < a.Hout) && (ox < a.Wout);
+        pixi[pt] = ok[pt] ? __mul24(oy, a.Wout) + ox : -1;
         po[pt] = ((size_t)b * a.Hout + oy) * a.Wout + ox;
     }
     f32x4 bias4[CT];
@@ -372,7 +604,16 @@ __global__ __launch_bounds__(256, (PT == 8 ? (CT <= 3 ? 3 : 2) : 1)) void conv_i
         for (int pt = 0; pt < PT; ++pt) ok[pt] = ok[pt] && acc[0][pt][0] == 12345.678f;
     }
     if constexpr (!F2) {
+#if MI355_F16_DIET
+        if (exp_flags & 4) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) pixi[pt] = ok[pt] ? pixi[pt] : -1;
+        }
+        const OutF16 o = make_out_f16(a.dst, a.dst_cs, a.img_dst, a.res, a.res_cs, a.img_res, b, a.Cout, a.act, a.out_f32);
+        store_tiles_f16_v2<PT, CT>(o, acc, bias4, lane, ct0, pixi);
+#else
         store_tiles_f16<PT, CT>(a, acc, bias4, lane, ct0, po, ok);
+#endif
     } else {
         // ---- first-stage image -> LDS behind the halo tile, fp16, pixel stride ldp2 = 32 * cib2 + 8 halfs ----
         _Float16* y1 = lds_h + 2 * a.lds_buf_floats;
@@ -391,8 +632,7 @@ __global__ __launch_bounds__(256, (PT == 8 ? (CT <= 3 ? 3 : 2) : 1)) void conv_i
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 if (ct0 + ct >= a.n_ctiles) continue;
-                f32x4 v = acc[ct][pt] + bias4[ct];
-                if (a.act) { v[0] = fast_silu(v[0]); v[1] = fast_silu(v[1]); v[2] = fast_silu(v[2]); v[3] = fast_silu(v[3]); }
+                const f32x4 v = bias_act4(acc[ct][pt], bias4[ct], a.act);
                 f16x4 o;
                 o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
                 *(f16x4*)(y1 + p * a.ldp2 + tile_cout0(ct0 + ct, g, pairs1)) = o;
@@ -406,6 +646,9 @@ __global__ __launch_bounds__(256, (PT == 8 ? (CT <= 3 ? 3 : 2) : 1)) void conv_i
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) x2[pt] = ((wp * PT + pt) * 16 + (lane & 15)) * a.ldp2 + 8 * g;
         const bool pairs2 = conv_f16_pairs(a.Cout2);
+#if MI355_F16_DIET
+        const OutF16 o2 = make_out_f16(a.dst2, a.dst2_cs, a.Hout * a.Wout * a.dst2_cs, nullptr, 0, 0, b, a.Cout2, a.act2, a.out2_f32);
+#endif
         for (int c2 = 2 * wc; c2 < a.n_ctiles2; c2 += 2 * WC) {
             f32x4 acc2[2][PT];
             const _Float16* w2[2];
@@ -428,7 +671,11 @@ __global__ __launch_bounds__(256, (PT == 8 ? (CT <= 3 ? 3 : 2) : 1)) void conv_i
                     acc2[1][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xv, acc2[1][pt], 0, 0, 0);
                 }
             }
+#if MI355_F16_DIET
+            store_tiles_f16_v2<PT, 2>(o2, acc2, b2, lane, c2, pixi);
+#else
             store_tiles_f16<PT, 2>(a2, acc2, b2, lane, c2, po, ok);
+#endif
         }
     }
 }

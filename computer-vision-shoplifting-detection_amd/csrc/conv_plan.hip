@@ -322,6 +322,23 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
         if (e_src >= lim || e_dst >= lim || e_dst2 >= lim) return "conv: image too large for the 32-bit offsets of conv_igemm_f32";
     }
     a.img_src = a.Hin * a.Win * a.src_cs; a.img_dst = a.Hout * a.Wout * a.dst_cs; a.img_res = a.Hout * a.Wout * a.res_cs;
+    a.THin = THin;
+    {
+        const int row_slots = a.TWin << a.ck4_shift;
+        a.st_rpi = row_slots >= 256 ? 1 : 256 / row_slots;
+        a.st_nseg = row_slots >= 256 ? (row_slots + 255) / 256 : 1;
+        a.inv_row_slots = 1.0f / (float)row_slots;
+    }
+    if (half && (p.version == 1 || p.f2)) {
+        // conv_igemm_f16 (round 3): source / destination / residual images behind buffer descriptors with 32-bit byte offsets and
+        // the drop marker 0x80000000 -- every image must stay below 2^31 bytes, and a source row below 2^24 bytes (24-bit multiply)
+        const long long lim = 1ll << 31;
+        const long long esz_out = c.out_f32 ? 4 : 2, esz2 = c.f2_out_f32 ? 4 : 2;
+        const long long b_src = (long long)a.Hin * a.Win * a.src_cs * 2, b_dst = (long long)a.Hout * a.Wout * std::max(a.dst_cs, a.res_cs) * esz_out;
+        const long long b_dst2 = p.f2 ? (long long)a.Hout * a.Wout * a.dst2_cs * esz2 : 0;
+        if (b_src >= lim || b_dst >= lim || b_dst2 >= lim || (long long)a.Win * a.src_cs * 2 >= (1ll << 24) && c.k != 1)
+            return "conv: image too large for the 32-bit offsets of conv_igemm_f16";
+    }
     out->lds = p.lds;
     out->a = a;
     out->CT = p.CT; out->WP = p.WP; out->version = p.version;

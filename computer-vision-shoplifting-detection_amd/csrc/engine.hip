@@ -1462,6 +1462,17 @@ static int infer_impl(mi355_yolo* h, const uint8_t* src, bool src_on_device, int
         cmask = h->d_cmask;
     }
 
+    // Small synchronous calls (the reference's frame-by-frame loop, model.py:38): the greedy NMS kernel writes its rows and
+    // counts straight into the pinned host buffers -- no compaction kernels, no copy-engine hand-overs (five stream operations,
+    // ~45 us of a 425-us frame at batch 1), one stream synchronisation.  MI355_DIRECT_ROWS=0 keeps the copy path.
+    const bool single_chunk = n <= nb;
+    static const bool direct_rows_on = !(getenv("MI355_DIRECT_ROWS") && atoi(getenv("MI355_DIRECT_ROWS")) == 0);
+    const bool direct_host = !async_out && single_chunk && n <= 16 && direct_rows_on;
+    mi355_det* host_rows_dev = nullptr; int* host_counts_dev = nullptr;
+    if (direct_host) {
+        HIPCHK(hipHostGetDevicePointer((void**)&host_rows_dev, h->h_rows, 0));
+        HIPCHK(hipHostGetDevicePointer((void**)&host_counts_dev, h->h_counts, 0));
+    }
     Prof pf{h};
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     for (int s = 0, ci = 0; s < n; s += nb, ++ci) {
@@ -1487,12 +1498,18 @@ static int infer_impl(mi355_yolo* h, const uint8_t* src, bool src_on_device, int
         na.scale_back = 1; na.gain = (float)g.gain; na.pad_x = (float)g.pad_x; na.pad_y = (float)g.pad_y;
         na.kpad_x = (float)g.kpad_x; na.kpad_y = (float)g.kpad_y; na.orig_w = (float)width; na.orig_h = (float)height;
         na.out_rows = h->d_rows + (size_t)s * max_det;
-        // counts for this chunk are written at [s, s+m); the sort kernel's scratch counts at [.. + m)
-        na.out_counts = h->d_counts + s;
-        // nms kernels use out_counts[B..2B) as scratch: point them past the real counts
+        if (direct_host) {                       // rows and counts straight into the pinned host buffers (slot layout: frame i at i * max_det)
+            na.out_rows = host_rows_dev;
+            na.host_counts = host_counts_dev;
+        }
         if (pf.begin(K_NMS)) return fail(MI355_EHIP, "event");
-        {
-            // temporary counts block: [2n .. 2n + 2*chunk)
+        if (single_chunk) {
+            // one chunk: the sort kernels' scratch [n, 3n) lies inside the counts allocation (2n + 3 * chunk ints, n <= chunk)
+            na.out_counts = h->d_counts;
+            KCHK(launch_nms(na, h->stream));
+        } else {
+            // counts of this chunk belong at [s, s + m), but the sort kernels use out_counts[B, 3B) as scratch: they run on a
+            // temporary block [2n, 2n + 3 * chunk) and the counts are copied into place
             int* tmp = h->d_counts + 2 * n;
             NmsArgs nb_args = na; nb_args.out_counts = tmp;
             KCHK(launch_nms(nb_args, h->stream));
@@ -1508,6 +1525,15 @@ static int infer_impl(mi355_yolo* h, const uint8_t* src, bool src_on_device, int
         HIPCHK(hipMemcpyAsync(dev_total, h->d_offsets + n, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
         h->async_pending = true;
         return MI355_OK;
+    }
+    if (direct_host) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int i = 0; i < n; ++i) {
+            const int c = std::min(h->h_counts[i], cap);
+            out_counts[i] = c;
+            std::memcpy(out_rows + (size_t)i * cap, h->h_rows + (size_t)i * max_det, (size_t)c * sizeof(mi355_det));
+        }
+        return collect_timing(h, pf, n);
     }
     // rows -> host: compact on the GPU first (a frame keeps counts[i] of its max_det slots; copying the slots would be 35 MB
     // per 512 frames), then two small copies: the counts, and sum(counts) rows

@@ -452,36 +452,52 @@ __global__ __launch_bounds__(64 * NMS_WAVES) void nms_greedy_kernel(NmsArgs a, c
         __syncthreads();                                            // the kept arrays are complete before the next chunk reads them
     }
     __syncthreads();
-    if (threadIdx.x == 0) a.out_counts[b] = nk;
-    mi355_det* rows = (mi355_det*)a.out_rows + (size_t)b * a.max_det;
-    for (int k = threadIdx.x; k < nk; k += 64 * NMS_WAVES) {
+    if (threadIdx.x == 0) {
+        a.out_counts[b] = nk;
+        if (a.host_counts) a.host_counts[b] = nk;       // small synchronous calls: the count goes straight to pinned host memory too
+    }
+    // Rows, one 32-bit word per thread step: consecutive lanes write consecutive words of a row, so the stores coalesce whether the
+    // destination is HBM or -- small synchronous calls, where a copy engine hand-over costs more than the kernels -- pinned host
+    // memory (out_rows then points there).  Every word is computed with the expression order of A.6 (xywh2xyxy, pad, gain, clip).
+    constexpr int RW = (int)(sizeof(mi355_det) / 4);
+    static_assert(sizeof(mi355_det) == 4 * (7 + MI355_MAX_KPT_FLOATS), "row words: x1 y1 x2 y2 conf cls anchor kpt[]");
+    unsigned* rows_w = (unsigned*)((mi355_det*)a.out_rows + (size_t)b * a.max_det);
+    const int nkf = a.nk < MI355_MAX_KPT_FLOATS ? a.nk : MI355_MAX_KPT_FLOATS;
+    const int kd = a.kdim > 0 ? a.kdim : 1;
+    for (int idx = threadIdx.x; idx < nk * RW; idx += 64 * NMS_WAVES) {
+        const int k = idx / RW, q = idx - k * RW;
         const int an = kan[k];
         const float* p = pred + (size_t)an * a.no;
-        const float hw = p[2] / 2.0f, hh = p[3] / 2.0f;
-        float x1 = p[0] - hw, y1 = p[1] - hh, x2 = p[0] + hw, y2 = p[1] + hh;
-        if (a.scale_back) {
-            x1 -= a.pad_x; y1 -= a.pad_y; x2 -= a.pad_x; y2 -= a.pad_y;
-            x1 /= a.gain; y1 /= a.gain; x2 /= a.gain; y2 /= a.gain;
-            x1 = fminf(fmaxf(x1, 0.f), a.orig_w); y1 = fminf(fmaxf(y1, 0.f), a.orig_h);
-            x2 = fminf(fmaxf(x2, 0.f), a.orig_w); y2 = fminf(fmaxf(y2, 0.f), a.orig_h);
-        }
-        mi355_det& r = rows[k];
-        r.x1 = x1; r.y1 = y1; r.x2 = x2; r.y2 = y2;
-        r.conf = best[an].x; r.cls = (int)best[an].y; r.anchor_idx = an;
-        const int nkf = a.nk < MI355_MAX_KPT_FLOATS ? a.nk : MI355_MAX_KPT_FLOATS;
-        const float* kp = p + 4 + a.nc;
-        const int kd = a.kdim > 0 ? a.kdim : 1;
-        for (int q = 0; q < nkf; ++q) {
-            float v = kp[q];
-            if (a.scale_back && (q % kd) < 2) {
-                const bool isx = (q % kd) == 0;
+        unsigned w = 0u;
+        if (q < 4) {
+            const bool isx = (q & 1) == 0;
+            const float half_ext = (isx ? p[2] : p[3]) / 2.0f;
+            const float c = isx ? p[0] : p[1];
+            float v = q < 2 ? c - half_ext : c + half_ext;
+            if (a.scale_back) {
+                v -= isx ? a.pad_x : a.pad_y;
+                v /= a.gain;
+                v = fminf(fmaxf(v, 0.f), isx ? a.orig_w : a.orig_h);
+            }
+            w = __float_as_uint(v);
+        } else if (q == 4) {
+            w = __float_as_uint(best[an].x);
+        } else if (q == 5) {
+            w = (unsigned)(int)best[an].y;
+        } else if (q == 6) {
+            w = (unsigned)an;
+        } else if (q - 7 < nkf) {
+            const int j = q - 7;
+            float v = p[4 + a.nc + j];
+            if (a.scale_back && (j % kd) < 2) {
+                const bool isx = (j % kd) == 0;
                 v -= isx ? a.kpad_x : a.kpad_y;
                 v /= a.gain;
                 v = fminf(fmaxf(v, 0.f), isx ? a.orig_w : a.orig_h);
             }
-            r.kpt[q] = v;
+            w = __float_as_uint(v);
         }
-        for (int q = nkf; q < MI355_MAX_KPT_FLOATS; ++q) r.kpt[q] = 0.f;
+        rows_w[idx] = w;
     }
 }
 

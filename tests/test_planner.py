@@ -4,9 +4,16 @@ import pytest
 from cvsd_amd import ops
 
 
-def test_small_pointwise_conv_is_offered_every_kernel_family():
-    v = ops.plan_versions(8, 80, 80, 128, 64, 1)
+def test_pointwise_conv_is_offered_every_kernel_family():
+    v = ops.plan_versions(64, 80, 80, 128, 64, 1)
     assert {1, 3, 4} <= set(v)
+
+
+def test_latency_bound_pointwise_conv_is_not_offered_the_pipelined_kernel():
+    """A few frames per pass: the persistent pipelined kernel (v4) never won there and crowded the streaming kernel's variants
+    out of the timed candidates, so it is only offered where the conv needs its fused upsample (conv_plan.hip)."""
+    v = ops.plan_versions(1, 80, 80, 128, 64, 1)
+    assert {1, 3} <= set(v) and 4 not in v
 
 
 def test_3x3_conv_is_offered_staged_and_fused_plans():
