@@ -552,6 +552,7 @@ def main() -> None:
         del m2, host, frames
         torch.cuda.empty_cache()
         line["configs"] = [measure_config(*c) for c in EXTRA_CONFIGS]                      # every GPU timing first ...
+        line["track_pipeline"] = track_pipeline()
         if want_cpu:                                                                        # ... then the CPU reference runs and the parity figures
             m3 = YOLO(blob, device=local_rank, batch_chunk=args.chunk)
             line["cpu_baseline"] = cpu_baseline(args, sd, frames_np, m3)
@@ -562,6 +563,37 @@ def main() -> None:
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def track_pipeline(n_frames: int = 160) -> dict:
+    """The reference's frame loop end to end (`model.track(frame, persist=True, ...)` per frame, /root/reference/model.py:38):
+    detector at batch 1 + BoT-SORT with its sparse-optical-flow motion compensation, on a synthetic 320x240 clip under a panning
+    camera (UCF-Crime's frame size).  Frames start on the host, as cv2.VideoCapture hands them over.  Three tracker set-ups: the
+    compensation's frame preparation and Lucas-Kanade step on the GPU (what model.track does), on the host (gmc_device=None: the
+    round-2/3a state), and switched off."""
+    import numpy as np
+    from cvsd_amd import YOLO
+    from cvsd_amd.tracker import BYTETracker
+    from cvsd_amd.weights import build_from_state_dict
+    from tools import synth
+    _, sd = synth.synthetic_checkpoint("yolov8n", seed=0)
+    model = YOLO(build_from_state_dict("yolov8n", sd), batch_chunk=1)
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, size=(256, 320 + 3 * n_frames + 16, 3), dtype=np.uint8)
+    base = ((base.astype(np.uint16) + np.roll(base, 1, 0) + np.roll(base, 1, 1) + np.roll(base, (1, 1), (0, 1))) // 4).astype(np.uint8)
+    frames = [np.ascontiguousarray(base[8:248, 3 * k:3 * k + 320]) for k in range(n_frames)]
+    out = {"workload": f"yolov8n model.track loop, {n_frames - 8} frames of 320x240 (host frames), conf 0.1, BoT-SORT defaults (sparseOptFlow GMC, <= 1000 corners)",
+           "unit": "frames/s"}
+    for key, make in (("gmc_on_gpu", lambda: BYTETracker(gmc_device=model.device)), ("gmc_on_host", lambda: BYTETracker(gmc_device=None)),
+                      ("gmc_off", lambda: BYTETracker(gmc_method=None))):
+        model._tracker = make()
+        for f in frames[:8]:
+            model.track(f, persist=True, conf=0.1)
+        t0 = time.perf_counter()
+        for f in frames[8:]:
+            model.track(f, persist=True, conf=0.1)
+        out[key] = round((n_frames - 8) / (time.perf_counter() - t0), 1)
+    return out
 
 
 def cpu_baseline(args, sd, frames_np, model):

@@ -84,6 +84,10 @@ SIGNATURES = {
     "mi355_plan_query": (C.c_int, [C.c_int] * 13 + [_i32p, C.c_int, _i32p]),
     "mi355_gmc_pyr_lk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                    C.c_double, C.c_void_p, C.c_void_p]),
+    "mi355_gmc_pyr_lk_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "mi355_gmc_prepare_device": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355_op_stem": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_int, C.c_int, C.c_void_p]),
     "mi355_letterbox_shape": (C.c_int, [C.c_int, C.c_int, C.c_int, _i32p, _i32p]),

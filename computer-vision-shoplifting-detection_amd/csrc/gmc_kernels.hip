@@ -1,0 +1,388 @@
+// BoT-SORT global motion compensation on the GPU: pyramidal Lucas-Kanade tracking of sparse corners between two gray frames
+// (what cv2.calcOpticalFlowPyrLK does for ultralytics/trackers/utils/gmc.py:GMC.apply_sparseoptflow, reached from
+// /root/reference/model.py:38 through model.track).  The algorithm and its parameters are stated once, in numpy, in
+// cvsd_amd/gmc.py:calc_optical_flow_pyr_lk_numpy; csrc/gmc_host.cpp is the same arithmetic as host loops.  On the host the
+// 1000-corner budget of goodFeaturesToTrack costs 27 us per point -- 10-27 ms per frame, thirty times the whole detector pass
+// (0.42 ms at batch 1), so the reference's frame loop (model.track -> CSV) ran at the tracker's pace.  Here every point is one
+// wavefront: its 21 x 21 window is 441 pixels = 7 per lane, the window's I / Ix / Iy samples stay in registers for all
+// iterations of a level, the 2 x 2 normal equations are wave reductions, all in float64 (the same formulae as the host code;
+// window sums are associated differently -- lane-wise then butterfly -- so results agree to rounding, not bit for bit).
+// The pyramids (5-tap Gaussian pyrDown, integer arithmetic: exact) are built by a kernel per level.
+#include "../../include/mi355_yolo.h"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kMaxLevels = 8;          // pyramid levels held (level 0 = the frame)
+constexpr int kMaxPer = 16;            // window pixels per lane: win <= 31 (961 = 15.02 * 64)
+
+__device__ __forceinline__ int reflect101(int i, int n) {          // BORDER_REFLECT_101, any distance (as the host code)
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+
+// cv2.pyrDown on uint8: separable [1 4 6 4 1] / 16 twice, reflect-101 borders, every second pixel, (s + 128) >> 8
+__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* src, int h, int w, uint8_t* dst, int nh, int nw) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nh * nw) return;
+    const int y = idx / nw, x = idx - y * nw;
+    const int k[5] = {1, 4, 6, 4, 1};
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const uint8_t* row = src + (size_t)reflect101(2 * y + i - 2, h) * w;
+        int r = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) r += k[j] * row[reflect101(2 * x + j - 2, w)];
+        s += k[i] * r;
+    }
+    dst[idx] = (uint8_t)((s + 128) >> 8);
+}
+
+struct LkArgs {
+    const uint8_t* prev[kMaxLevels]; const uint8_t* cur[kMaxLevels];
+    int h[kMaxLevels], w[kMaxLevels];
+    int top, n, win, max_iters, width, height;
+    double eps2, min_eig;
+    const float* pts; float* next; uint8_t* status;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// value of plane `kind` (0 = intensity, 1 = Scharr d/dx, 2 = Scharr d/dy of the same image) at integer position (y, x) of the
+// reflect-padded plane: the host code pads the plane of gradients, so the position is reflected first and the stencil
+// reflects its own neighbours
+template <int KIND>
+__device__ __forceinline__ double plane_at(const uint8_t* img, int h, int w, int y, int x) {
+    y = reflect101(y, h); x = reflect101(x, w);
+    if (KIND == 0) return (double)img[(size_t)y * w + x];
+    const int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h), xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+    auto A = [&](int yy, int xx) { return (int)img[(size_t)yy * w + xx]; };
+    if (KIND == 1) return (double)(3 * (A(ym, xp) - A(ym, xm)) + 10 * (A(y, xp) - A(y, xm)) + 3 * (A(yp, xp) - A(yp, xm)));
+    return (double)(3 * (A(yp, xm) - A(ym, xm)) + 10 * (A(yp, x) - A(ym, x)) + 3 * (A(yp, xp) - A(ym, xp)));
+}
+
+// this lane's samples of the win x win bilinear patch whose top-left corner is (px - half, py - half): window pixel k = lane + 64 j
+template <int KIND>
+__device__ __forceinline__ void patch(const uint8_t* img, int h, int w, double px, double py, int win, int lane, double (&out)[kMaxPer], int per) {
+    const int half = win / 2;
+    const double x = px - half, y = py - half;
+    const double fx = floor(x), fy = floor(y);
+    const int ix = (int)fx, iy = (int)fy;
+    const double ax = x - fx, ay = y - fy;
+    const double w00 = (1 - ay) * (1 - ax), w01 = (1 - ay) * ax, w10 = ay * (1 - ax), w11 = ay * ax;
+    const int W2 = win * win;
+#pragma unroll
+    for (int j = 0; j < kMaxPer; ++j) {
+        if (j >= per) break;
+        const int k = lane + 64 * j;
+        double v = 0.0;
+        if (k < W2) {
+            const int r = k / win, c = k - r * win;
+            const int yy = iy + r, xx = ix + c;
+            v = w00 * plane_at<KIND>(img, h, w, yy, xx) + w01 * plane_at<KIND>(img, h, w, yy, xx + 1) +
+                w10 * plane_at<KIND>(img, h, w, yy + 1, xx) + w11 * plane_at<KIND>(img, h, w, yy + 1, xx + 1);
+        }
+        out[j] = v;
+    }
+}
+
+// one wavefront per point; block = 4 wavefronts
+__global__ __launch_bounds__(256) void lk_kernel(LkArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.n) return;
+    const int win = a.win, half = win / 2, W2 = win * win;
+    const int per = (W2 + 63) / 64;
+    const double s = 1.0 / (double)(1 << 20);                    // OpenCV's scaling of the gradient products
+    const double p0x = (double)a.pts[2 * i], p0y = (double)a.pts[2 * i + 1];
+    bool ok = true;
+    double nx = 0, ny = 0;
+    double I[kMaxPer], Ix[kMaxPer], Iy[kMaxPer], J[kMaxPer];
+    for (int l = a.top; l >= 0; --l) {
+        const int h = a.h[l], w = a.w[l];
+        const double px = p0x / (double)(1 << l), py = p0y / (double)(1 << l);
+        if (l == a.top) { nx = px; ny = py; } else { nx *= 2.0; ny *= 2.0; }
+        const double tlx = floor(px - half), tly = floor(py - half);
+        const bool inside = tlx >= -win && tlx < w && tly >= -win && tly < h;
+        if (!inside) { if (l == 0) ok = false; continue; }
+        const double cx = fmin(fmax(px, (double)-half), (double)(w - 1 + half));
+        const double cy = fmin(fmax(py, (double)-half), (double)(h - 1 + half));
+        patch<0>(a.prev[l], h, w, cx, cy, win, lane, I, per);
+        patch<1>(a.prev[l], h, w, cx, cy, win, lane, Ix, per);
+        patch<2>(a.prev[l], h, w, cx, cy, win, lane, Iy, per);
+        double a11 = 0, a12 = 0, a22 = 0;
+#pragma unroll
+        for (int j = 0; j < kMaxPer; ++j) {
+            if (j >= per) break;
+            a11 += Ix[j] * Ix[j]; a12 += Ix[j] * Iy[j]; a22 += Iy[j] * Iy[j];
+        }
+        a11 = wave_sum(a11) * s; a12 = wave_sum(a12) * s; a22 = wave_sum(a22) * s;
+        const double det = a11 * a22 - a12 * a12;
+        const double mineig = (a22 + a11 - sqrt((a11 - a22) * (a11 - a22) + 4 * a12 * a12)) / (2.0 * W2);
+        if (!(mineig >= a.min_eig) || !(det >= (double)1.1920928955078125e-07)) { if (l == 0) ok = false; continue; }
+        double pdx = 0, pdy = 0;
+        for (int it = 0; it < a.max_iters; ++it) {
+            const double qx = floor(nx - half), qy = floor(ny - half);
+            if (!(qx >= -win && qx < w && qy >= -win && qy < h)) { if (l == 0) ok = false; break; }
+            const double ccx = fmin(fmax(nx, (double)-half), (double)(w - 1 + half));
+            const double ccy = fmin(fmax(ny, (double)-half), (double)(h - 1 + half));
+            patch<0>(a.cur[l], h, w, ccx, ccy, win, lane, J, per);
+            double b1 = 0, b2 = 0;
+#pragma unroll
+            for (int j = 0; j < kMaxPer; ++j) {
+                if (j >= per) break;
+                const double d = (J[j] - I[j]) * 32.0;           // lanes past the window hold zeros in all four arrays
+                b1 += d * Ix[j]; b2 += d * Iy[j];
+            }
+            b1 = wave_sum(b1) * s; b2 = wave_sum(b2) * s;
+            const double dx = (a12 * b2 - a22 * b1) / det, dy = (a12 * b1 - a11 * b2) / det;
+            nx += dx; ny += dy;
+            if (dx * dx + dy * dy <= a.eps2) break;
+            if (it > 0 && fabs(dx + pdx) < 0.01 && fabs(dy + pdy) < 0.01) { nx -= dx * 0.5; ny -= dy * 0.5; break; }
+            pdx = dx; pdy = dy;
+        }
+    }
+    if (ok && (nx < 0 || ny < 0 || nx >= a.width || ny >= a.height)) ok = false;
+    if (lane == 0) {
+        a.next[2 * i] = (float)nx; a.next[2 * i + 1] = (float)ny;
+        a.status[i] = ok ? 1 : 0;
+    }
+}
+
+// ---- frame preparation: cvtColor(BGR2GRAY) + resize(INTER_LINEAR) + the corner map of goodFeaturesToTrack -------------------
+// gmc.py states these in numpy (bgr_to_gray, resize_linear, good_features_to_track); the kernels evaluate the same expressions
+// in the same order (integers for luma and resize; float64 for the structure tensor, its sums taken in numpy's order), so the
+// corner list is the numpy one.
+
+// gray = (1868 B + 9617 G + 4899 R + 8192) >> 14, then INTER_LINEAR with 11-bit coefficients (tables from the host: source index,
+// two taps per output column / row), both passes in cv2's fixed point: ((c0 * (h0 >> 4)) >> 16) + ((c1 * (h1 >> 4)) >> 16) + 2) >> 2
+__global__ __launch_bounds__(256) void gray_resize_kernel(const uint8_t* bgr, int H, int W, const int* xtab, const int* ytab, uint8_t* out, int oh, int ow,
+                                                          int resize) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= oh * ow) return;
+    const int y = idx / ow, x = idx - y * ow;
+    auto gray = [&](int yy, int xx) {
+        const uint8_t* p = bgr + ((size_t)yy * W + xx) * 3;
+        return (int)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14);
+    };
+    if (!resize) { out[idx] = (uint8_t)gray(y, x); return; }
+    const int xi = xtab[3 * x], xa0 = xtab[3 * x + 1], xa1 = xtab[3 * x + 2];
+    const int yi = ytab[3 * y], yb0 = ytab[3 * y + 1], yb1 = ytab[3 * y + 2];
+    const int xj = min(xi + 1, W - 1), yj = min(yi + 1, H - 1);
+    const int h0 = gray(yi, xi) * xa0 + gray(yi, xj) * xa1;
+    const int h1 = gray(yj, xi) * xa0 + gray(yj, xj) * xa1;
+    int v = (((yb0 * (h0 >> 4)) >> 16) + ((yb1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    out[idx] = (uint8_t)v;
+}
+
+// cornerMinEigenVal (3x3 Sobel scaled by 1 / (4 * block * 255), block x block box sums of the products, smaller eigenvalue) as
+// float32, and its maximum over the plane (non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* g, int h, int w, float* eig, unsigned* max_bits) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    float e = 0.f;
+    if (idx < h * w) {
+        const int y = idx / w, x = idx - y * w;
+        const double sc = 1.0 / (4.0 * 3.0 * 255.0);
+        auto G = [&](int yy, int xx) { return (double)g[(size_t)reflect101(yy, h) * w + reflect101(xx, w)]; };
+        double sxx = 0.0, sxy = 0.0, syy = 0.0;                 // Python's sum(): 0 + p00 + p01 + ... in (i, j) row-major order
+#pragma unroll
+        for (int i = -1; i <= 1; ++i)
+#pragma unroll
+            for (int j = -1; j <= 1; ++j) {
+                const int yy = reflect101(y + i, h), xx = reflect101(x + j, w);     // the product arrays are reflect-padded
+                const double dx = ((G(yy - 1, xx + 1) - G(yy - 1, xx - 1)) + 2 * (G(yy, xx + 1) - G(yy, xx - 1)) + (G(yy + 1, xx + 1) - G(yy + 1, xx - 1))) * sc;
+                const double dy = ((G(yy + 1, xx - 1) - G(yy - 1, xx - 1)) + 2 * (G(yy + 1, xx) - G(yy - 1, xx)) + (G(yy + 1, xx + 1) - G(yy - 1, xx + 1))) * sc;
+                sxx += dx * dx; sxy += dx * dy; syy += dy * dy;
+            }
+        const double a = sxx * 0.5, b = sxy, c = syy * 0.5;
+        e = (float)((a + c) - sqrt((a - c) * (a - c) + b * b));
+        eig[idx] = e;
+    }
+    // block maximum, then one atomic per block
+    float m = e > 0.f ? e : 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(max_bits, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+}
+
+// THRESH_TOZERO at quality * max, 3x3 non-maximum suppression (a corner equals the maximum of its neighbourhood), image border excluded
+__global__ __launch_bounds__(256) void corner_mask_kernel(const float* eig, int h, int w, const unsigned* max_bits, double quality, uint8_t* ok) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= h * w) return;
+    const int y = idx / w, x = idx - y * w;
+    const float mx = __uint_as_float(*max_bits);
+    const float thr = (float)((double)mx * quality);
+    auto T = [&](int yy, int xx) {
+        if (yy < 0 || yy >= h || xx < 0 || xx >= w) return -INFINITY;
+        const float v = eig[(size_t)yy * w + xx];
+        return v > thr ? v : 0.f;
+    };
+    const float v = T(y, x);
+    float d = -INFINITY;
+#pragma unroll
+    for (int i = -1; i <= 1; ++i)
+#pragma unroll
+        for (int j = -1; j <= 1; ++j) d = fmaxf(d, T(y + i, x + j));
+    const bool keep = mx > 0.f && v != 0.f && v == d && y > 0 && y < h - 1 && x > 0 && x < w - 1;
+    ok[idx] = keep ? 1 : 0;
+}
+
+// per-device scratch, grow-only; calls are serialised (the tracker is sequential per video)
+struct GmcCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint8_t* d_planes = nullptr; size_t planes_cap = 0;        // [prev pyramid | cur pyramid]
+    float* d_pts = nullptr; float* d_next = nullptr; uint8_t* d_status = nullptr; int pts_cap = 0;
+    uint8_t* h_pin = nullptr; size_t pin_cap = 0;              // pinned staging: frames + points in, points + status out
+    uint8_t* d_front = nullptr; size_t front_cap = 0;          // frame preparation: [bgr | gray | eig | ok | tables | max]
+    uint8_t* h_front = nullptr; size_t hfront_cap = 0;
+};
+std::mutex g_mu;
+GmcCtx g_ctx[16];
+
+#define GCHK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return -2; } } while (0)
+
+}  // namespace
+
+// Same contract as mi355_gmc_pyr_lk (gmc_host.cpp) with the work done on GPU `device`: 0 = ok, -1 = bad argument, -2 = HIP error.
+extern "C" int mi355_gmc_pyr_lk_device(int device, const uint8_t* prev, const uint8_t* cur, int height, int width, const float* pts, int n,
+                                       int win, int max_level, int max_iters, double eps, double min_eig, float* next_pts, uint8_t* status) {
+    if (!prev || !cur || height <= 0 || width <= 0 || n < 0 || (n > 0 && (!pts || !next_pts || !status)) || win < 3 || !(win & 1) || win > 31 ||
+        device < 0 || device >= 16 || max_level < 0)
+        return -1;
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> lock(g_mu);
+    GCHK(hipSetDevice(device));
+    GmcCtx& c = g_ctx[device];
+    if (!c.stream) { GCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking)); c.device = device; }
+    // level geometry (buildOpticalFlowPyramid stops at levels not larger than the window)
+    int hs[kMaxLevels], ws[kMaxLevels], levels = 1;
+    hs[0] = height; ws[0] = width;
+    for (int l = 0; l < max_level && levels < kMaxLevels; ++l) {
+        const int nh = (hs[levels - 1] + 1) / 2, nw = (ws[levels - 1] + 1) / 2;
+        if (nh <= win || nw <= win) break;
+        hs[levels] = nh; ws[levels] = nw; ++levels;
+    }
+    size_t off[kMaxLevels], pyr_bytes = 0;
+    for (int l = 0; l < levels; ++l) { off[l] = pyr_bytes; pyr_bytes += ((size_t)hs[l] * ws[l] + 255) & ~(size_t)255; }
+    if (c.planes_cap < 2 * pyr_bytes) {
+        if (c.d_planes) (void)hipFree(c.d_planes);
+        c.d_planes = nullptr; c.planes_cap = 0;
+        GCHK(hipMalloc(&c.d_planes, 2 * pyr_bytes)); c.planes_cap = 2 * pyr_bytes;
+    }
+    if (c.pts_cap < n) {
+        if (c.d_pts) (void)hipFree(c.d_pts); if (c.d_next) (void)hipFree(c.d_next); if (c.d_status) (void)hipFree(c.d_status);
+        c.d_pts = c.d_next = nullptr; c.d_status = nullptr; c.pts_cap = 0;
+        const int cap = std::max(1024, n);
+        GCHK(hipMalloc(&c.d_pts, (size_t)cap * 8)); GCHK(hipMalloc(&c.d_next, (size_t)cap * 8)); GCHK(hipMalloc(&c.d_status, (size_t)cap));
+        c.pts_cap = cap;
+    }
+    const size_t frame = (size_t)height * width;
+    const size_t pin_need = 2 * frame + (size_t)n * 8 + (size_t)n * 8 + (size_t)n + 64;
+    if (c.pin_cap < pin_need) {
+        if (c.h_pin) (void)hipHostFree(c.h_pin);
+        c.h_pin = nullptr; c.pin_cap = 0;
+        GCHK(hipHostMalloc(&c.h_pin, pin_need)); c.pin_cap = pin_need;
+    }
+    uint8_t* h_prev = c.h_pin; uint8_t* h_cur = h_prev + frame;
+    float* h_pts = (float*)(c.h_pin + ((2 * frame + 15) & ~(size_t)15));               // 16-byte aligned behind the frames
+    float* h_next = h_pts + 2 * (size_t)n;
+    uint8_t* h_status = (uint8_t*)(h_next + 2 * (size_t)n);
+    std::memcpy(h_prev, prev, frame); std::memcpy(h_cur, cur, frame); std::memcpy(h_pts, pts, (size_t)n * 8);
+    uint8_t* dp = c.d_planes; uint8_t* dc = c.d_planes + pyr_bytes;
+    GCHK(hipMemcpyAsync(dp, h_prev, frame, hipMemcpyHostToDevice, c.stream));
+    GCHK(hipMemcpyAsync(dc, h_cur, frame, hipMemcpyHostToDevice, c.stream));
+    GCHK(hipMemcpyAsync(c.d_pts, h_pts, (size_t)n * 8, hipMemcpyHostToDevice, c.stream));
+    LkArgs a{};
+    for (int l = 0; l < levels; ++l) { a.prev[l] = dp + off[l]; a.cur[l] = dc + off[l]; a.h[l] = hs[l]; a.w[l] = ws[l]; }
+    for (int l = 1; l < levels; ++l) {
+        const int np = hs[l] * ws[l];
+        hipLaunchKernelGGL(pyr_down_kernel, dim3((np + 255) / 256), dim3(256), 0, c.stream, dp + off[l - 1], hs[l - 1], ws[l - 1], dp + off[l], hs[l], ws[l]);
+        hipLaunchKernelGGL(pyr_down_kernel, dim3((np + 255) / 256), dim3(256), 0, c.stream, dc + off[l - 1], hs[l - 1], ws[l - 1], dc + off[l], hs[l], ws[l]);
+    }
+    a.top = levels - 1; a.n = n; a.win = win; a.max_iters = max_iters; a.width = width; a.height = height;
+    a.eps2 = eps * eps; a.min_eig = min_eig;
+    a.pts = c.d_pts; a.next = c.d_next; a.status = c.d_status;
+    hipLaunchKernelGGL(lk_kernel, dim3((n + 3) / 4), dim3(256), 0, c.stream, a);
+    GCHK(hipGetLastError());
+    GCHK(hipMemcpyAsync(h_next, c.d_next, (size_t)n * 8, hipMemcpyDeviceToHost, c.stream));
+    GCHK(hipMemcpyAsync(h_status, c.d_status, (size_t)n, hipMemcpyDeviceToHost, c.stream));
+    GCHK(hipStreamSynchronize(c.stream));
+    std::memcpy(next_pts, h_next, (size_t)n * 8); std::memcpy(status, h_status, (size_t)n);
+    return 0;
+}
+
+// Frame preparation of GMC.apply on GPU `device`: BGR frame [height][width][3] -> gray plane of (height / downscale) x (width /
+// downscale) (cv2.cvtColor + cv2.resize INTER_LINEAR, bit for bit the fixed-point arithmetic gmc.py states), the float32
+// min-eigenvalue map of cornerMinEigenVal and the 0/1 mask of the corners goodFeaturesToTrack keeps before it orders them
+// (quality threshold, 3x3 non-maximum suppression, border excluded).  xtab / ytab: per output column / row (source index, tap 0,
+// tap 1) as gmc._linear_coeffs gives them; ignored when downscale == 1.  Outputs are host buffers of oh * ow elements.
+extern "C" int mi355_gmc_prepare_device(int device, const uint8_t* bgr, int height, int width, int oh, int ow, const int* xtab, const int* ytab,
+                                        double quality, uint8_t* gray_out, float* eig_out, uint8_t* ok_out) {
+    if (!bgr || height <= 0 || width <= 0 || oh <= 0 || ow <= 0 || !gray_out || !eig_out || !ok_out || device < 0 || device >= 16) return -1;
+    const int resize = !(oh == height && ow == width);
+    if (resize && (!xtab || !ytab)) return -1;
+    std::lock_guard<std::mutex> lock(g_mu);
+    GCHK(hipSetDevice(device));
+    GmcCtx& c = g_ctx[device];
+    if (!c.stream) { GCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking)); c.device = device; }
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t nb = (size_t)height * width * 3, np = (size_t)oh * ow;
+    const size_t o_gray = al(nb), o_eig = o_gray + al(np), o_ok = o_eig + al(np * 4), o_xt = o_ok + al(np), o_yt = o_xt + al((size_t)ow * 12),
+                 o_max = o_yt + al((size_t)oh * 12), total = o_max + 256;
+    if (c.front_cap < total) {
+        if (c.d_front) (void)hipFree(c.d_front);
+        c.d_front = nullptr; c.front_cap = 0;
+        GCHK(hipMalloc(&c.d_front, total)); c.front_cap = total;
+    }
+    const size_t h_in = al(nb) + al((size_t)ow * 12) + al((size_t)oh * 12), h_total = h_in + al(np) + al(np * 4) + al(np);
+    if (c.hfront_cap < h_total) {
+        if (c.h_front) (void)hipHostFree(c.h_front);
+        c.h_front = nullptr; c.hfront_cap = 0;
+        GCHK(hipHostMalloc(&c.h_front, h_total)); c.hfront_cap = h_total;
+    }
+    uint8_t* hp = c.h_front;
+    uint8_t* h_bgr = hp; uint8_t* h_xt = hp + al(nb); uint8_t* h_yt = h_xt + al((size_t)ow * 12);
+    uint8_t* h_gray = hp + h_in; uint8_t* h_eig = h_gray + al(np); uint8_t* h_ok = h_eig + al(np * 4);
+    std::memcpy(h_bgr, bgr, nb);
+    GCHK(hipMemcpyAsync(c.d_front, h_bgr, nb, hipMemcpyHostToDevice, c.stream));
+    if (resize) {
+        std::memcpy(h_xt, xtab, (size_t)ow * 12); std::memcpy(h_yt, ytab, (size_t)oh * 12);
+        GCHK(hipMemcpyAsync(c.d_front + o_xt, h_xt, (size_t)ow * 12, hipMemcpyHostToDevice, c.stream));
+        GCHK(hipMemcpyAsync(c.d_front + o_yt, h_yt, (size_t)oh * 12, hipMemcpyHostToDevice, c.stream));
+    }
+    GCHK(hipMemsetAsync(c.d_front + o_max, 0, 4, c.stream));
+    const unsigned blocks = (unsigned)((np + 255) / 256);
+    hipLaunchKernelGGL(gray_resize_kernel, dim3(blocks), dim3(256), 0, c.stream, c.d_front, height, width, (const int*)(c.d_front + o_xt),
+                       (const int*)(c.d_front + o_yt), c.d_front + o_gray, oh, ow, resize);
+    hipLaunchKernelGGL(min_eig_kernel, dim3(blocks), dim3(256), 0, c.stream, c.d_front + o_gray, oh, ow, (float*)(c.d_front + o_eig),
+                       (unsigned*)(c.d_front + o_max));
+    hipLaunchKernelGGL(corner_mask_kernel, dim3(blocks), dim3(256), 0, c.stream, (const float*)(c.d_front + o_eig), oh, ow,
+                       (const unsigned*)(c.d_front + o_max), quality, c.d_front + o_ok);
+    GCHK(hipGetLastError());
+    GCHK(hipMemcpyAsync(h_gray, c.d_front + o_gray, np, hipMemcpyDeviceToHost, c.stream));
+    GCHK(hipMemcpyAsync(h_eig, c.d_front + o_eig, np * 4, hipMemcpyDeviceToHost, c.stream));
+    GCHK(hipMemcpyAsync(h_ok, c.d_front + o_ok, np, hipMemcpyDeviceToHost, c.stream));
+    GCHK(hipStreamSynchronize(c.stream));
+    std::memcpy(gray_out, h_gray, np); std::memcpy(eig_out, h_eig, np * 4); std::memcpy(ok_out, h_ok, np);
+    return 0;
+}

@@ -258,7 +258,8 @@ class YOLO:
         kwargs.pop("batch", None)
         conf = 0.1 if conf is None else conf
         if self._tracker is None or not persist:
-            self._tracker = BYTETracker()
+            # the frame preparation and the optical flow of its motion compensation run on the engine's GPU (csrc/gmc_kernels.hip)
+            self._tracker = BYTETracker(gmc_device=getattr(self, "device", None))
         batch, originals = self._as_batch(source)
         results = []
         for i in range(int(batch.shape[0])):

@@ -105,6 +105,53 @@ def good_features_to_track(gray: np.ndarray, max_corners: int = MAX_CORNERS, qua
     return np.stack([xs[order], ys[order]], axis=1).astype(np.float32)
 
 
+_TABLES: dict = {}
+
+
+def _coeff_table(dn: int, sn: int) -> np.ndarray:
+    """int32 [dn, 3] rows (source index, tap 0, tap 1) of :func:`_linear_coeffs`, kept per (dn, sn): a video has one frame size"""
+    key = (dn, sn)
+    if key not in _TABLES:
+        if len(_TABLES) > 64:
+            _TABLES.clear()
+        _TABLES[key] = np.ascontiguousarray(np.stack(_linear_coeffs(dn, sn), axis=1), dtype=np.int32)
+    return _TABLES[key]
+
+
+def prepare_frame(raw_frame: np.ndarray, downscale: int = 2, device: Optional[int] = None, max_corners: int = MAX_CORNERS,
+                  quality: float = QUALITY_LEVEL) -> Tuple[np.ndarray, np.ndarray]:
+    """The first three OpenCV calls of ``GMC.apply_sparseoptflow`` for one BGR frame -> (gray plane at 1 / downscale, corners
+    float32 [n, 2] strongest first).  ``device=None``: the numpy statements above.  ``device=k``: csrc/gmc_kernels.hip on GPU k
+    (luma + resize in the same fixed point, the structure tensor in float64 with its sums in numpy's order, threshold and
+    non-maximum suppression), then the ordering of the kept corners here -- the same plane and the same corner list."""
+    h, w = raw_frame.shape[:2]
+    dh, dw = (h // downscale, w // downscale) if downscale > 1 else (h, w)
+    if device is None or raw_frame.ndim != 3:
+        gray = bgr_to_gray(raw_frame) if raw_frame.ndim == 3 else raw_frame
+        if downscale > 1:
+            gray = resize_linear(gray, dw, dh)
+        return gray, good_features_to_track(gray, max_corners, quality)
+    import ctypes as C
+    from . import _lib
+    frame = np.ascontiguousarray(raw_frame, dtype=np.uint8)
+    xt = yt = None
+    if downscale > 1:
+        xt, yt = _coeff_table(dw, w), _coeff_table(dh, h)
+    gray = np.empty((dh, dw), np.uint8)
+    eig = np.empty((dh, dw), np.float32)
+    ok = np.empty((dh, dw), np.uint8)
+    rc = _lib.lib().mi355_gmc_prepare_device(int(device), frame.ctypes.data, h, w, dh, dw, xt.ctypes.data if xt is not None else None,
+                                             yt.ctypes.data if yt is not None else None, float(quality), gray.ctypes.data, eig.ctypes.data,
+                                             ok.ctypes.data)
+    if rc == -2:
+        raise RuntimeError(f"mi355_gmc_prepare_device: HIP error on device {device}")
+    if rc != 0:
+        raise ValueError("mi355_gmc_prepare_device: bad argument")
+    ys, xs = np.nonzero(ok)
+    order = np.argsort(-eig[ys, xs], kind="stable")[:max_corners]
+    return gray, np.stack([xs[order], ys[order]], axis=1).astype(np.float32).reshape(-1, 2)
+
+
 # ------------------------------------------------------------------------------------------------- pyramidal Lucas-Kanade
 def _pyr_down(img: np.ndarray) -> np.ndarray:
     """cv2.pyrDown on uint8: separable [1 4 6 4 1] / 16, reflect-101 borders, every second pixel, round to nearest."""
@@ -138,10 +185,12 @@ def _patches(img_pad: np.ndarray, pts: np.ndarray, pad: int, win: int) -> np.nda
 
 
 def calc_optical_flow_pyr_lk(prev: np.ndarray, cur: np.ndarray, pts: np.ndarray, win: int = LK_WIN, levels: int = LK_LEVELS,
-                             max_iters: int = LK_MAX_ITERS, eps: float = LK_EPS, min_eig: float = LK_MIN_EIG
-                             ) -> Tuple[np.ndarray, np.ndarray]:
-    """The tracker the product runs: the host C++ loops of csrc/gmc_host.cpp (same arithmetic as
-    :func:`calc_optical_flow_pyr_lk_numpy`, which states the algorithm and is kept as its cross-check; 50-100x faster)."""
+                             max_iters: int = LK_MAX_ITERS, eps: float = LK_EPS, min_eig: float = LK_MIN_EIG,
+                             device: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """The tracker the product runs.  ``device=None``: the host C++ loops of csrc/gmc_host.cpp (same arithmetic as
+    :func:`calc_optical_flow_pyr_lk_numpy`, which states the algorithm and is kept as its cross-check; 50-100x faster than it).
+    ``device=k``: the HIP kernels of csrc/gmc_kernels.hip on GPU k (one wavefront per point; what ``model.track`` uses: on the
+    host the 1000-corner budget costs 10-27 ms per frame, thirty times the detector pass)."""
     import ctypes as C
     from . import _lib
     prev, cur = np.ascontiguousarray(prev, dtype=np.uint8), np.ascontiguousarray(cur, dtype=np.uint8)
@@ -150,8 +199,15 @@ def calc_optical_flow_pyr_lk(prev: np.ndarray, cur: np.ndarray, pts: np.ndarray,
     p = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 2)
     nxt = np.zeros_like(p)
     status = np.zeros(len(p), dtype=np.uint8)
-    rc = _lib.lib().mi355_gmc_pyr_lk(prev.ctypes.data, cur.ctypes.data, prev.shape[0], prev.shape[1], p.ctypes.data, len(p), int(win), int(levels),
-                                     int(max_iters), float(eps), float(min_eig), nxt.ctypes.data, status.ctypes.data)
+    if device is None:
+        rc = _lib.lib().mi355_gmc_pyr_lk(prev.ctypes.data, cur.ctypes.data, prev.shape[0], prev.shape[1], p.ctypes.data, len(p), int(win), int(levels),
+                                         int(max_iters), float(eps), float(min_eig), nxt.ctypes.data, status.ctypes.data)
+    else:
+        rc = _lib.lib().mi355_gmc_pyr_lk_device(int(device), prev.ctypes.data, cur.ctypes.data, prev.shape[0], prev.shape[1], p.ctypes.data, len(p),
+                                                int(win), int(levels), int(max_iters), float(eps), float(min_eig), nxt.ctypes.data,
+                                                status.ctypes.data)
+    if rc == -2:
+        raise RuntimeError(f"mi355_gmc_pyr_lk_device: HIP error on device {device} (no GPU? the host routine is device=None)")
     if rc != 0:
         raise ValueError("mi355_gmc_pyr_lk: bad argument")
     return nxt, status.astype(bool)
@@ -257,6 +313,12 @@ def _similarity_from_pairs(p: np.ndarray, q: np.ndarray) -> np.ndarray:
     return np.array([[a, -b, qm[0] - (a * pm[0] - b * pm[1])], [b, a, qm[1] - (b * pm[0] + a * pm[1])]])
 
 
+def _same_point(a, b) -> bool:
+    """np.allclose(a, b) for two 2-vectors (rtol 1e-5, atol 1e-8) without its array machinery (30 us a call, twice per draw)"""
+    ax, ay, bx, by = float(a[0]), float(a[1]), float(b[0]), float(b[1])
+    return abs(ax - bx) <= 1e-8 + 1e-5 * abs(bx) and abs(ay - by) <= 1e-8 + 1e-5 * abs(by)
+
+
 def estimate_affine_partial_2d(src: np.ndarray, dst: np.ndarray, threshold: float = RANSAC_THRESHOLD, confidence: float = RANSAC_CONFIDENCE,
                                max_iters: int = RANSAC_MAX_ITERS, seed: int = 0) -> Tuple[Optional[np.ndarray], np.ndarray]:
     """cv2.estimateAffinePartial2D(src, dst, RANSAC): 4-degree-of-freedom similarity + inlier mask, or (None, zeros)."""
@@ -271,7 +333,7 @@ def estimate_affine_partial_2d(src: np.ndarray, dst: np.ndarray, threshold: floa
     while it < iters:
         it += 1
         i, j = rng.choice(n, 2, replace=False)
-        if np.allclose(src[i], src[j]) or np.allclose(dst[i], dst[j]):
+        if _same_point(src[i], src[j]) or _same_point(dst[i], dst[j]):
             continue
         H = _similarity_from_pairs(src[[i, j]], dst[[i, j]])
         err = ((src @ H[:, :2].T + H[:, 2] - dst) ** 2).sum(1)
@@ -294,7 +356,8 @@ class GMC:
     """``GMC(method="sparseOptFlow", downscale=2).apply(frame_bgr) -> 2x3`` (float64); identity on the first frame, when too
     few points survive, or when ``method`` is None / "none"."""
 
-    def __init__(self, method: Optional[str] = "sparseOptFlow", downscale: int = 2):
+    def __init__(self, method: Optional[str] = "sparseOptFlow", downscale: int = 2, device: Optional[int] = None):
+        self.device = device                   # None: Lucas-Kanade on the host; k: on GPU k (model.track passes the engine's device)
         if method in ("none", "None"):
             method = None
         if method not in (None, "sparseOptFlow"):
@@ -310,15 +373,11 @@ class GMC:
         H = np.eye(2, 3)
         if self.method is None or raw_frame is None:
             return H
-        frame = bgr_to_gray(raw_frame) if raw_frame.ndim == 3 else raw_frame
-        h, w = frame.shape
-        if self.downscale > 1:
-            frame = resize_linear(frame, w // self.downscale, h // self.downscale)
-        points = good_features_to_track(frame)
+        frame, points = prepare_frame(raw_frame, self.downscale, self.device)
         if self.prev_frame is None or self.prev_points is None or self.prev_frame.shape != frame.shape:
             self.prev_frame, self.prev_points = frame.copy(), points
             return H
-        nxt, status = calc_optical_flow_pyr_lk(self.prev_frame, frame, self.prev_points)
+        nxt, status = calc_optical_flow_pyr_lk(self.prev_frame, frame, self.prev_points, device=self.device)
         p, q = self.prev_points[status], nxt[status]
         if len(p) > 4:
             est, _ = estimate_affine_partial_2d(p, q)
@@ -330,10 +389,12 @@ class GMC:
         return H
 
 
-def warp_kalman(mean: np.ndarray, cov: np.ndarray, H: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+def warp_kalman(mean: np.ndarray, cov: np.ndarray, H: np.ndarray, R8: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
     """``STrack.multi_gmc`` for one track: the rotation/scale block acts on every (x, y)-like pair of the state
-    (cx cy | w h | vcx vcy | vw vh), the translation on the centre only; P <- R8 P R8'."""
-    R8 = np.kron(np.eye(4), H[:2, :2])
+    (cx cy | w h | vcx vcy | vw vh), the translation on the centre only; P <- R8 P R8'.  ``R8`` = kron(I4, H[:2, :2]) may be
+    handed in by a caller that warps many tracks with one H."""
+    if R8 is None:
+        R8 = np.kron(np.eye(4), H[:2, :2])
     m = R8 @ mean
     m[:2] += H[:2, 2]
     return m, R8 @ cov @ R8.T

@@ -148,9 +148,9 @@ class BYTETracker:
     """``update(det [N,6] = x1,y1,x2,y2,conf,cls) -> [M,8] = x1,y1,x2,y2,id,score,cls,idx`` (idx = row of ``det``), one call
     per frame, EVERY frame (an empty frame still ages the lost tracks)."""
 
-    def __init__(self, frame_rate: int = 30, gmc_method: Optional[str] = "sparseOptFlow"):
+    def __init__(self, frame_rate: int = 30, gmc_method: Optional[str] = "sparseOptFlow", gmc_device: Optional[int] = None):
         from .gmc import GMC
-        self.gmc = GMC(gmc_method)             # BOTSORT.__init__: GMC(method=args.gmc_method); None = identity
+        self.gmc = GMC(gmc_method, device=gmc_device)   # BOTSORT.__init__: GMC(method=args.gmc_method); None = identity
         self.frame_id = 0
         self.max_time_lost = int(frame_rate / 30.0 * TRACK_BUFFER)
         self._live: List[Track] = []          # tracked (confirmed or awaiting confirmation), in report order
@@ -210,8 +210,9 @@ class BYTETracker:
             except Exception:                                   # byte_tracker.py bypasses errors of the gmc module the same way
                 warp = np.eye(2, 3)
             if not np.array_equal(warp, np.eye(2, 3)):
+                R8 = np.kron(np.eye(4), warp[:2, :2])
                 for t in pool + tentative:
-                    t.mean, t.cov = warp_kalman(t.mean, t.cov, warp)
+                    t.mean, t.cov = warp_kalman(t.mean, t.cov, warp, R8)
 
         touched: List[Track] = []        # matched this frame and previously tracked ("activated")
         revived: List[Track] = []        # matched this frame and previously lost ("refound")

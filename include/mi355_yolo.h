@@ -223,6 +223,19 @@ int  mi355_plan_query(int n, int h, int w, int cin, int cout, int k, int stride,
  * pts / next_pts: [n][2] (x, y).  Returns 0, or -1 on a bad argument. */
 int  mi355_gmc_pyr_lk(const uint8_t* prev, const uint8_t* cur, int height, int width, const float* pts, int n, int win,
                       int max_level, int max_iters, double eps, double min_eig, float* next_pts, uint8_t* status);
+/* The same on GPU `device` (csrc/gmc_kernels.hip: one wavefront per point, float64, pyramids built on the GPU; host buffers in and
+ * out).  On the host the 1000-corner budget costs 10-27 ms per frame -- thirty times the detector pass -- so model.track() hands
+ * its tracker the engine's device.  Results agree with the host routine to rounding (window sums are associated differently).
+ * win <= 31.  Returns 0, -1 (bad argument) or -2 (HIP error). */
+int  mi355_gmc_pyr_lk_device(int device, const uint8_t* prev, const uint8_t* cur, int height, int width, const float* pts, int n, int win,
+                             int max_level, int max_iters, double eps, double min_eig, float* next_pts, uint8_t* status);
+/* Frame preparation of the same motion compensation on GPU `device`: BGR frame -> gray plane of oh x ow (cv2.cvtColor(BGR2GRAY) +
+ * cv2.resize(INTER_LINEAR) in their fixed-point arithmetic; xtab / ytab = per output column / row {source index, tap 0, tap 1} with
+ * 11-bit taps, unused when oh x ow is the frame size), the float32 min-eigenvalue map of cv2.goodFeaturesToTrack (3x3 Sobel, 3x3
+ * block) and the 0/1 mask of the corners it keeps (quality threshold against the map's maximum, 3x3 non-maximum suppression,
+ * border excluded); the caller orders the kept corners by strength.  Host buffers in and out.  0, -1 (bad argument), -2 (HIP error). */
+int  mi355_gmc_prepare_device(int device, const uint8_t* bgr, int height, int width, int oh, int ow, const int* xtab, const int* ytab,
+                              double quality, uint8_t* gray_out, float* eig_out, uint8_t* ok_out);
 /* The u8 stem: letterboxed BGR frames -> (x/255, RGB) -> conv k x k stride s (pad k/2, or 2 for k=6) + bias + SiLU. */
 int  mi355_op_stem(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias,
                    int cout, int k, int stride, float* y);

@@ -166,6 +166,27 @@ def test_batch_larger_than_chunk_and_single_frame(v8n):
         np.testing.assert_array_equal(r.anchor_idx, one.anchor_idx)
 
 
+def test_rows_written_straight_to_host_equal_the_copied_rows(v8n_pose):
+    """Calls of at most 16 frames in one chunk: the greedy NMS kernel writes rows and counts into pinned host memory itself
+    (engine.hip: direct_host); larger calls compact on the GPU and copy.  Same frames, both routes: identical rows, keypoint words
+    included, on either side of the 16-frame boundary."""
+    from cvsd_amd import YOLO
+    from tools import synth
+    m = YOLO.from_state_dict("yolov8n-pose", v8n_pose[1], batch_chunk=32)
+    frames = synth.synthetic_frames(17, 96, 128, seed=21)
+    copied = m.predict(frames, conf=0.05, imgsz=128)               # 17 frames: compaction + copies
+    direct = m.predict(frames[:16], conf=0.05, imgsz=128)          # 16 frames: straight to host
+    singles = [m.predict(frames[i], conf=0.05, imgsz=128)[0] for i in (0, 7, 16)]
+    assert sum(len(r.anchor_idx) for r in copied) > 0
+    for a, b in zip(copied[:16], direct):
+        np.testing.assert_array_equal(a.anchor_idx, b.anchor_idx)
+        np.testing.assert_array_equal(a.boxes.data.numpy(), b.boxes.data.numpy())
+        np.testing.assert_array_equal(a.keypoints.data.numpy(), b.keypoints.data.numpy())
+    for i, one in zip((0, 7, 16), singles):
+        np.testing.assert_array_equal(copied[i].boxes.data.numpy(), one.boxes.data.numpy())
+        np.testing.assert_array_equal(copied[i].keypoints.data.numpy(), one.keypoints.data.numpy())
+
+
 def test_device_resident_input(v8n):
     m = _model("yolov8n", v8n)
     from tools import synth

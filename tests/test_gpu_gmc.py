@@ -1,0 +1,101 @@
+"""GPU Lucas-Kanade of BoT-SORT's motion compensation (csrc/gmc_kernels.hip) against the numpy statement of the algorithm and the
+host C++ routine, and the tracker running on it (``model.track`` hands its tracker the engine's device)."""
+import time
+
+import numpy as np
+import pytest
+
+from cvsd_amd import gmc
+
+pytestmark = pytest.mark.gpu
+
+
+def _smooth_noise(h, w, seed, sigma=2.0):
+    """non-periodic texture: white noise blurred by a separable Gaussian, stretched to 8 bits (as tests/test_gmc.py)"""
+    rng = np.random.default_rng(seed)
+    a = rng.normal(size=(h, w))
+    r = int(3 * sigma)
+    k = np.exp(-0.5 * (np.arange(-r, r + 1) / sigma) ** 2)
+    k /= k.sum()
+    a = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 1, a)
+    a = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 0, a)
+    a = (a - a.min()) / (a.max() - a.min())
+    return np.rint(a * 255).astype(np.uint8)
+
+
+def _pair(h=150, w=200, dy=3, dx=-5, seeds=(3, 4)):
+    big = ((_smooth_noise(h + 50, w + 60, seed=seeds[0], sigma=2.0).astype(np.int32) + _smooth_noise(h + 50, w + 60, seed=seeds[1], sigma=8.0)) // 2
+           ).astype(np.uint8)
+    return np.ascontiguousarray(big[20:20 + h, 30:30 + w]), np.ascontiguousarray(big[20 + dy:20 + dy + h, 30 + dx:30 + dx + w])
+
+
+@pytest.mark.parametrize("shape,shift", [((150, 200), (3, -5)), ((120, 160), (-7, 9)), ((97, 131), (2, 2)), ((360, 640), (11, -14))])
+def test_device_lucas_kanade_is_the_numpy_statement_of_the_algorithm(shape, shift):
+    """same points kept, same positions to 1e-3 px (window sums are associated differently: lane-wise, then a butterfly), on even,
+    odd and larger planes (the pyramid's reflect-101 borders and odd halvings included)"""
+    prev, cur = _pair(shape[0], shape[1], shift[0], shift[1])
+    pts = gmc.good_features_to_track(prev)[:400]
+    # corners near the border too: windows that hang over the edge read reflected pixels
+    edge = np.array([[1.0, 1.0], [shape[1] - 2.0, 2.0], [3.5, shape[0] - 2.5], [shape[1] - 1.0, shape[0] - 1.0]], np.float32)
+    pts = np.concatenate([pts, edge])
+    a, sa = gmc.calc_optical_flow_pyr_lk(prev, cur, pts, device=0)
+    h, sh = gmc.calc_optical_flow_pyr_lk(prev, cur, pts)
+    assert (sa == sh).mean() > 0.995
+    both = sa & sh
+    assert both.sum() > 100 and np.abs(a[both] - h[both]).max() < 1e-3
+    if shape[0] <= 150:                                            # the numpy statement takes seconds per call
+        b, sb = gmc.calc_optical_flow_pyr_lk_numpy(prev, cur, pts[:120])
+        ok = sa[:120] & sb
+        assert (sa[:120] == sb).mean() > 0.99 and np.abs(a[:120][ok] - b[ok]).max() < 1e-3
+    # the recovered motion is the planted shift
+    d = (a[both] - pts[both])
+    assert np.abs(np.median(d[:, 0]) - (-shift[1])) < 0.05 and np.abs(np.median(d[:, 1]) - (-shift[0])) < 0.05
+
+
+@pytest.mark.parametrize("shape,downscale", [((240, 320), 2), ((241, 323), 2), ((120, 160), 1), ((360, 640), 2), ((90, 121), 3)])
+def test_device_frame_preparation_gives_numpys_plane_and_corner_list(shape, downscale):
+    """luma, INTER_LINEAR resize, Shi-Tomasi corner map, threshold and non-maximum suppression on the GPU: the same gray plane byte
+    for byte and the same corners in the same order as the numpy statements (odd sizes, no resize, a non-integer scale)"""
+    rng = np.random.default_rng(shape[0] + downscale)
+    g = _smooth_noise(shape[0], shape[1], seed=11, sigma=1.5)
+    frame = np.stack([g, np.roll(g, 3, 1), 255 - g], axis=2)
+    frame = np.clip(frame.astype(np.int32) + rng.integers(-6, 7, size=frame.shape), 0, 255).astype(np.uint8)
+    gray_h, pts_h = gmc.prepare_frame(frame, downscale, None)
+    gray_d, pts_d = gmc.prepare_frame(frame, downscale, 0)
+    np.testing.assert_array_equal(gray_d, gray_h)
+    assert len(pts_h) > 50
+    np.testing.assert_array_equal(pts_d, pts_h)
+    # a flat frame has no corners
+    flat = np.full((shape[0], shape[1], 3), 90, np.uint8)
+    assert gmc.prepare_frame(flat, downscale, 0)[1].shape == (0, 2)
+
+
+def test_device_routine_rejects_bad_arguments_and_takes_empty_input():
+    prev, cur = _pair()
+    assert gmc.calc_optical_flow_pyr_lk(prev, cur, np.zeros((0, 2), np.float32), device=0)[0].shape == (0, 2)
+    with pytest.raises(ValueError):
+        gmc.calc_optical_flow_pyr_lk(prev, cur, np.ones((3, 2), np.float32), win=33, device=0)      # windows above 31 x 31: host only
+    with pytest.raises(ValueError):
+        gmc.calc_optical_flow_pyr_lk(prev, cur, np.ones((3, 2), np.float32), device=99)
+
+
+def test_tracker_on_the_device_keeps_the_ids_of_the_host_tracker():
+    """a panning camera over static people: the tracker whose optical flow runs on the GPU returns the boxes and ids of the host one"""
+    from cvsd_amd.tracker import BYTETracker
+    h, w = 240, 320
+    big = ((_smooth_noise(h + 40, w + 400, seed=7, sigma=2.0).astype(np.int32) + _smooth_noise(h + 40, w + 400, seed=8, sigma=6.0)) // 2).astype(np.uint8)
+    people = np.array([[60, 60, 100, 180], [150, 40, 190, 170], [240, 80, 275, 200]], np.float32)
+    host, dev = BYTETracker(), BYTETracker(gmc_device=0)
+    t_host = t_dev = 0.0
+    for k in range(12):
+        off = 9 * k
+        frame = np.repeat(big[20:20 + h, off:off + w, None], 3, axis=2)
+        det = np.concatenate([people - [off, 0, off, 0] + 100 * np.array([1, 0, 1, 0]), np.full((3, 1), 0.9, np.float32), np.zeros((3, 1), np.float32)], axis=1
+                             ).astype(np.float32)
+        t0 = time.perf_counter(); a = host.update(det, frame); t1 = time.perf_counter(); b = dev.update(det, frame); t2 = time.perf_counter()
+        t_host += t1 - t0; t_dev += t2 - t1
+        assert a.shape == b.shape
+        if len(a):
+            np.testing.assert_array_equal(a[:, 4], b[:, 4])                  # track ids
+            np.testing.assert_allclose(a[:, :4], b[:, :4], atol=2e-2)        # boxes after the compensated Kalman update
+    print(f"tracker update per frame: host {t_host / 12 * 1e3:.2f} ms, device {t_dev / 12 * 1e3:.2f} ms")
