@@ -88,6 +88,11 @@ SIGNATURES = {
                                           C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "mi355_gmc_prepare_device": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double,
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_gmc_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "mi355_gmc_destroy": (None, [C.c_void_p]),
+    "mi355_gmc_step_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]),
+    "mi355_gmc_step_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355_op_stem": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_int, C.c_int, C.c_void_p]),
     "mi355_letterbox_shape": (C.c_int, [C.c_int, C.c_int, C.c_int, _i32p, _i32p]),

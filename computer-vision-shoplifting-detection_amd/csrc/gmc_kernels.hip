@@ -101,18 +101,44 @@ __device__ __forceinline__ void patch(const uint8_t* img, int h, int w, double p
     }
 }
 
+// The iteration reads the current frame through a per-wavefront LDS copy of the neighbourhood it is walking in: (win + 1 + 2 M)^2
+// reflect-padded intensities as doubles, refilled only when the window's corner leaves the margin M.  The values are those
+// plane_at<0> returns, so the arithmetic -- and every bit of the result -- is that of reading global memory each time; what goes
+// away is four byte loads with reflected addresses per window pixel per iteration (three quarters of the kernel's instructions).
+constexpr int kMargin = 3;
+constexpr int kRegMax = 31 + 1 + 2 * kMargin;          // region side for the largest window
+
+__device__ __forceinline__ void fill_region(const uint8_t* img, int h, int w, int ry, int rx, int R, int lane, double* reg) {
+    for (int k = lane; k < R * R; k += 64) {
+        const int r = k / R, c = k - r * R;
+        reg[k] = plane_at<0>(img, h, w, ry + r, rx + c);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // one wavefront per point; block = 4 wavefronts
 __global__ __launch_bounds__(256) void lk_kernel(LkArgs a) {
+    __shared__ double region[4][kRegMax * kRegMax];
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= a.n) return;
+    double* reg = region[threadIdx.x >> 6];
     const int win = a.win, half = win / 2, W2 = win * win;
     const int per = (W2 + 63) / 64;
+    const int R = win + 1 + 2 * kMargin;
     const double s = 1.0 / (double)(1 << 20);                    // OpenCV's scaling of the gradient products
     const double p0x = (double)a.pts[2 * i], p0y = (double)a.pts[2 * i + 1];
     bool ok = true;
     double nx = 0, ny = 0;
-    double I[kMaxPer], Ix[kMaxPer], Iy[kMaxPer], J[kMaxPer];
+    double I[kMaxPer], Ix[kMaxPer], Iy[kMaxPer];
+    int koff[kMaxPer];                                           // this lane's window pixels as offsets inside the region
+#pragma unroll
+    for (int j = 0; j < kMaxPer; ++j) {
+        const int k = lane + 64 * j;
+        const int r = k / win, c = k - r * win;
+        koff[j] = (j < per && k < W2) ? r * R + c : -1;
+    }
     for (int l = a.top; l >= 0; --l) {
         const int h = a.h[l], w = a.w[l];
         const double px = p0x / (double)(1 << l), py = p0y / (double)(1 << l);
@@ -136,17 +162,35 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a) {
         const double mineig = (a22 + a11 - sqrt((a11 - a22) * (a11 - a22) + 4 * a12 * a12)) / (2.0 * W2);
         if (!(mineig >= a.min_eig) || !(det >= (double)1.1920928955078125e-07)) { if (l == 0) ok = false; continue; }
         double pdx = 0, pdy = 0;
+        int rx = 0, ry = 0; bool have_region = false;
         for (int it = 0; it < a.max_iters; ++it) {
             const double qx = floor(nx - half), qy = floor(ny - half);
             if (!(qx >= -win && qx < w && qy >= -win && qy < h)) { if (l == 0) ok = false; break; }
             const double ccx = fmin(fmax(nx, (double)-half), (double)(w - 1 + half));
             const double ccy = fmin(fmax(ny, (double)-half), (double)(h - 1 + half));
-            patch<0>(a.cur[l], h, w, ccx, ccy, win, lane, J, per);
+            // the window's top-left sample (as patch<0> derives it) and its bilinear weights
+            const double x = ccx - half, y = ccy - half;
+            const double fx = floor(x), fy = floor(y);
+            const int ix = (int)fx, iy = (int)fy;
+            const double ax = x - fx, ay = y - fy;
+            const double w00 = (1 - ay) * (1 - ax), w01 = (1 - ay) * ax, w10 = ay * (1 - ax), w11 = ay * ax;
+            if (!have_region || ix < rx || iy < ry || ix > rx + 2 * kMargin || iy > ry + 2 * kMargin) {
+                __builtin_amdgcn_wave_barrier();                   // every lane is done reading the old region
+                rx = ix - kMargin; ry = iy - kMargin;
+                fill_region(a.cur[l], h, w, ry, rx, R, lane, reg);
+                have_region = true;
+            }
+            const double* r0 = reg + (iy - ry) * R + (ix - rx);
             double b1 = 0, b2 = 0;
 #pragma unroll
             for (int j = 0; j < kMaxPer; ++j) {
                 if (j >= per) break;
-                const double d = (J[j] - I[j]) * 32.0;           // lanes past the window hold zeros in all four arrays
+                double Jv = 0.0;                                 // lanes past the window hold zeros in I / Ix / Iy too
+                if (koff[j] >= 0) {
+                    const double* q = r0 + koff[j];
+                    Jv = w00 * q[0] + w01 * q[1] + w10 * q[R] + w11 * q[R + 1];
+                }
+                const double d = (Jv - I[j]) * 32.0;
                 b1 += d * Ix[j]; b2 += d * Iy[j];
             }
             b1 = wave_sum(b1) * s; b2 = wave_sum(b2) * s;
@@ -156,6 +200,7 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a) {
             if (it > 0 && fabs(dx + pdx) < 0.01 && fabs(dy + pdy) < 0.01) { nx -= dx * 0.5; ny -= dy * 0.5; break; }
             pdx = dx; pdy = dy;
         }
+        __builtin_amdgcn_wave_barrier();
     }
     if (ok && (nx < 0 || ny < 0 || nx >= a.width || ny >= a.height)) ok = false;
     if (lane == 0) {
@@ -384,5 +429,159 @@ extern "C" int mi355_gmc_prepare_device(int device, const uint8_t* bgr, int heig
     GCHK(hipMemcpyAsync(h_ok, c.d_front + o_ok, np, hipMemcpyDeviceToHost, c.stream));
     GCHK(hipStreamSynchronize(c.stream));
     std::memcpy(gray_out, h_gray, np); std::memcpy(eig_out, h_eig, np * 4); std::memcpy(ok_out, h_ok, np);
+    return 0;
+}
+
+// ---- one motion-compensation step as two calls: enqueue, then collect ------------------------------------------------------------
+// model.track() enqueues the step for a frame BEFORE the detector runs on it and collects it when the tracker asks for the warp: the
+// frame preparation and the optical flow (0.7 ms for a thousand corners) then run beside the detector pass on a stream of their own
+// instead of after it.  The object keeps the previous frame's pyramid on the device (two slots, swapped per step).
+struct mi355_gmc {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint8_t* d_front = nullptr; size_t front_cap = 0;          // [bgr | eig | ok | x table | y table | max]
+    uint8_t* d_pyr[2] = {nullptr, nullptr}; size_t pyr_cap = 0;
+    int slot = 0; bool have_prev = false; int ph = 0, pw = 0;  // the slot and plane size of the last prepared frame
+    int tab_key[4] = {0, 0, 0, 0};                             // (height, width, oh, ow) the resize tables on the device belong to
+    float* d_pts = nullptr; float* d_next = nullptr; uint8_t* d_status = nullptr; int pts_cap = 0;
+    uint8_t* h_pin = nullptr; size_t pin_cap = 0;
+    // the pending step
+    bool pending = false; int oh = 0, ow = 0, n_lk = 0;
+    size_t o_hgray = 0, o_heig = 0, o_hok = 0, o_hnext = 0, o_hstatus = 0;
+};
+
+extern "C" int mi355_gmc_create(int device, mi355_gmc** out) {
+    if (!out || device < 0) return -1;
+    *out = nullptr;
+    GCHK(hipSetDevice(device));
+    mi355_gmc* g = new mi355_gmc();
+    g->device = device;
+    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); delete g; return -2; }
+    *out = g;
+    return 0;
+}
+
+extern "C" void mi355_gmc_destroy(mi355_gmc* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
+    if (g->d_front) (void)hipFree(g->d_front);
+    for (int i = 0; i < 2; ++i) if (g->d_pyr[i]) (void)hipFree(g->d_pyr[i]);
+    if (g->d_pts) (void)hipFree(g->d_pts); if (g->d_next) (void)hipFree(g->d_next); if (g->d_status) (void)hipFree(g->d_status);
+    if (g->h_pin) (void)hipHostFree(g->h_pin);
+    delete g;
+}
+
+// Enqueue one step: frame preparation of `bgr` (as mi355_gmc_prepare_device) and, when n_prev > 0, Lucas-Kanade tracking of the
+// n_prev points `prev_pts` from the PREVIOUS step's plane into this one (as mi355_gmc_pyr_lk_device; the previous step must have
+// prepared a plane of the same oh x ow).  Returns at once; nothing of `bgr` / `prev_pts` is read after the call returns.
+extern "C" int mi355_gmc_step_begin(mi355_gmc* g, const uint8_t* bgr, int height, int width, int oh, int ow, const int* xtab, const int* ytab,
+                                    double quality, const float* prev_pts, int n_prev, int win, int max_level, int max_iters, double eps,
+                                    double min_eig) {
+    if (!g || !bgr || height <= 0 || width <= 0 || oh <= 0 || ow <= 0 || n_prev < 0 || (n_prev > 0 && !prev_pts) || win < 3 || !(win & 1) || win > 31 ||
+        max_level < 0)
+        return -1;
+    const int resize = !(oh == height && ow == width);
+    if (resize && (!xtab || !ytab)) return -1;
+    if (g->pending) return -1;                                  // collect the previous step first
+    if (n_prev > 0 && !(g->have_prev && g->ph == oh && g->pw == ow)) return -1;
+    GCHK(hipSetDevice(g->device));
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t nb = (size_t)height * width * 3, np = (size_t)oh * ow;
+    // pyramid geometry of the oh x ow plane
+    int hs[kMaxLevels], ws[kMaxLevels], levels = 1;
+    hs[0] = oh; ws[0] = ow;
+    for (int l = 0; l < max_level && levels < kMaxLevels; ++l) {
+        const int nh = (hs[levels - 1] + 1) / 2, nw = (ws[levels - 1] + 1) / 2;
+        if (nh <= win || nw <= win) break;
+        hs[levels] = nh; ws[levels] = nw; ++levels;
+    }
+    size_t off[kMaxLevels], pyr_bytes = 0;
+    for (int l = 0; l < levels; ++l) { off[l] = pyr_bytes; pyr_bytes += al((size_t)hs[l] * ws[l]); }
+    if (g->pyr_cap < pyr_bytes) {
+        for (int i = 0; i < 2; ++i) { if (g->d_pyr[i]) (void)hipFree(g->d_pyr[i]); g->d_pyr[i] = nullptr; }
+        g->pyr_cap = 0; g->have_prev = false;
+        if (n_prev > 0) return -1;
+        GCHK(hipMalloc(&g->d_pyr[0], pyr_bytes)); GCHK(hipMalloc(&g->d_pyr[1], pyr_bytes)); g->pyr_cap = pyr_bytes;
+    }
+    const size_t o_eig = al(nb), o_ok = o_eig + al(np * 4), o_xt = o_ok + al(np), o_yt = o_xt + al((size_t)ow * 12), o_max = o_yt + al((size_t)oh * 12),
+                 total = o_max + 256;
+    if (g->front_cap < total) {
+        if (g->d_front) (void)hipFree(g->d_front);
+        g->d_front = nullptr; g->front_cap = 0; g->tab_key[0] = 0;
+        GCHK(hipMalloc(&g->d_front, total)); g->front_cap = total;
+    }
+    if (g->pts_cap < n_prev) {
+        if (g->d_pts) (void)hipFree(g->d_pts); if (g->d_next) (void)hipFree(g->d_next); if (g->d_status) (void)hipFree(g->d_status);
+        g->d_pts = g->d_next = nullptr; g->d_status = nullptr; g->pts_cap = 0;
+        const int cap = std::max(1024, n_prev);
+        GCHK(hipMalloc(&g->d_pts, (size_t)cap * 8)); GCHK(hipMalloc(&g->d_next, (size_t)cap * 8)); GCHK(hipMalloc(&g->d_status, (size_t)cap));
+        g->pts_cap = cap;
+    }
+    // pinned staging: [bgr | x table | y table | prev points] in, [gray | eig | ok | next points | status] out
+    const size_t i_xt = al(nb), i_yt = i_xt + al((size_t)ow * 12), i_pts = i_yt + al((size_t)oh * 12), i_end = i_pts + al((size_t)n_prev * 8);
+    g->o_hgray = i_end; g->o_heig = g->o_hgray + al(np); g->o_hok = g->o_heig + al(np * 4); g->o_hnext = g->o_hok + al(np);
+    g->o_hstatus = g->o_hnext + al((size_t)n_prev * 8);
+    const size_t pin_need = g->o_hstatus + al((size_t)n_prev) + 256;
+    if (g->pin_cap < pin_need) {
+        if (g->h_pin) (void)hipHostFree(g->h_pin);
+        g->h_pin = nullptr; g->pin_cap = 0;
+        GCHK(hipHostMalloc(&g->h_pin, pin_need)); g->pin_cap = pin_need;
+    }
+    uint8_t* hp = g->h_pin;
+    std::memcpy(hp, bgr, nb);
+    GCHK(hipMemcpyAsync(g->d_front, hp, nb, hipMemcpyHostToDevice, g->stream));
+    if (resize && !(g->tab_key[0] == height && g->tab_key[1] == width && g->tab_key[2] == oh && g->tab_key[3] == ow)) {
+        std::memcpy(hp + i_xt, xtab, (size_t)ow * 12); std::memcpy(hp + i_yt, ytab, (size_t)oh * 12);
+        GCHK(hipMemcpyAsync(g->d_front + o_xt, hp + i_xt, (size_t)ow * 12, hipMemcpyHostToDevice, g->stream));
+        GCHK(hipMemcpyAsync(g->d_front + o_yt, hp + i_yt, (size_t)oh * 12, hipMemcpyHostToDevice, g->stream));
+        g->tab_key[0] = height; g->tab_key[1] = width; g->tab_key[2] = oh; g->tab_key[3] = ow;
+    }
+    GCHK(hipMemsetAsync(g->d_front + o_max, 0, 4, g->stream));
+    const int nslot = g->slot ^ 1;
+    uint8_t* dc = g->d_pyr[nslot];
+    uint8_t* dp = g->d_pyr[g->slot];
+    const unsigned blocks = (unsigned)((np + 255) / 256);
+    hipLaunchKernelGGL(gray_resize_kernel, dim3(blocks), dim3(256), 0, g->stream, g->d_front, height, width, (const int*)(g->d_front + o_xt),
+                       (const int*)(g->d_front + o_yt), dc + off[0], oh, ow, resize);
+    hipLaunchKernelGGL(min_eig_kernel, dim3(blocks), dim3(256), 0, g->stream, dc + off[0], oh, ow, (float*)(g->d_front + o_eig),
+                       (unsigned*)(g->d_front + o_max));
+    hipLaunchKernelGGL(corner_mask_kernel, dim3(blocks), dim3(256), 0, g->stream, (const float*)(g->d_front + o_eig), oh, ow,
+                       (const unsigned*)(g->d_front + o_max), quality, g->d_front + o_ok);
+    for (int l = 1; l < levels; ++l) {
+        const int npx = hs[l] * ws[l];
+        hipLaunchKernelGGL(pyr_down_kernel, dim3((npx + 255) / 256), dim3(256), 0, g->stream, dc + off[l - 1], hs[l - 1], ws[l - 1], dc + off[l], hs[l], ws[l]);
+    }
+    if (n_prev > 0) {
+        std::memcpy(hp + i_pts, prev_pts, (size_t)n_prev * 8);
+        GCHK(hipMemcpyAsync(g->d_pts, hp + i_pts, (size_t)n_prev * 8, hipMemcpyHostToDevice, g->stream));
+        LkArgs a{};
+        for (int l = 0; l < levels; ++l) { a.prev[l] = dp + off[l]; a.cur[l] = dc + off[l]; a.h[l] = hs[l]; a.w[l] = ws[l]; }
+        a.top = levels - 1; a.n = n_prev; a.win = win; a.max_iters = max_iters; a.width = ow; a.height = oh;
+        a.eps2 = eps * eps; a.min_eig = min_eig;
+        a.pts = g->d_pts; a.next = g->d_next; a.status = g->d_status;
+        hipLaunchKernelGGL(lk_kernel, dim3((n_prev + 3) / 4), dim3(256), 0, g->stream, a);
+        GCHK(hipMemcpyAsync(hp + g->o_hnext, g->d_next, (size_t)n_prev * 8, hipMemcpyDeviceToHost, g->stream));
+        GCHK(hipMemcpyAsync(hp + g->o_hstatus, g->d_status, (size_t)n_prev, hipMemcpyDeviceToHost, g->stream));
+    }
+    GCHK(hipGetLastError());
+    GCHK(hipMemcpyAsync(hp + g->o_hgray, dc + off[0], np, hipMemcpyDeviceToHost, g->stream));
+    GCHK(hipMemcpyAsync(hp + g->o_heig, g->d_front + o_eig, np * 4, hipMemcpyDeviceToHost, g->stream));
+    GCHK(hipMemcpyAsync(hp + g->o_hok, g->d_front + o_ok, np, hipMemcpyDeviceToHost, g->stream));
+    g->slot = nslot; g->have_prev = true; g->ph = oh; g->pw = ow;
+    g->pending = true; g->oh = oh; g->ow = ow; g->n_lk = n_prev;
+    return 0;
+}
+
+// Collect the enqueued step: gray / eig / ok of oh * ow elements, next_pts [n_prev][2] and status [n_prev] (untouched when the step
+// had n_prev == 0).
+extern "C" int mi355_gmc_step_finish(mi355_gmc* g, uint8_t* gray_out, float* eig_out, uint8_t* ok_out, float* next_pts, uint8_t* status) {
+    if (!g || !g->pending || !gray_out || !eig_out || !ok_out || (g->n_lk > 0 && (!next_pts || !status))) return -1;
+    GCHK(hipSetDevice(g->device));
+    g->pending = false;
+    if (hipStreamSynchronize(g->stream) != hipSuccess) { (void)hipGetLastError(); g->have_prev = false; return -2; }
+    const size_t np = (size_t)g->oh * g->ow;
+    std::memcpy(gray_out, g->h_pin + g->o_hgray, np); std::memcpy(eig_out, g->h_pin + g->o_heig, np * 4); std::memcpy(ok_out, g->h_pin + g->o_hok, np);
+    if (g->n_lk > 0) { std::memcpy(next_pts, g->h_pin + g->o_hnext, (size_t)g->n_lk * 8); std::memcpy(status, g->h_pin + g->o_hstatus, (size_t)g->n_lk); }
     return 0;
 }

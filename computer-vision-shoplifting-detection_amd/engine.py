@@ -263,13 +263,16 @@ class YOLO:
         batch, originals = self._as_batch(source)
         results = []
         for i in range(int(batch.shape[0])):
+            frame = originals[i] if originals is not None else batch[i].cpu().numpy()
+            # the tracker's motion compensation for this frame (frame preparation + optical flow, a stream of its own on the GPU) is
+            # enqueued before the detector pass and collected inside tracker.update: the two share the GPU instead of queueing
+            self._tracker.gmc.begin(frame)
             res = self.predict(batch[i:i + 1], conf=conf, **kwargs)[0]
             if originals is not None:
                 res.orig_img = originals[i]
             # trackers/track.py:on_predict_postprocess_end: the tracker steps on EVERY frame (an empty frame still advances
             # frame_id, ages lost tracks against track_buffer and runs the Kalman predict); only the rewrite of the
             # result is skipped when no track comes back
-            frame = originals[i] if originals is not None else batch[i].cpu().numpy()
             tracks = self._tracker.update(res.boxes.data.numpy(), frame)   # trackers/track.py: tracker.update(det, im0)
             if len(tracks):
                 idx = tracks[:, -1].astype(int)

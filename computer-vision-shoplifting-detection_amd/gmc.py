@@ -354,10 +354,14 @@ def estimate_affine_partial_2d(src: np.ndarray, dst: np.ndarray, threshold: floa
 # ------------------------------------------------------------------------------------------------- the GMC object
 class GMC:
     """``GMC(method="sparseOptFlow", downscale=2).apply(frame_bgr) -> 2x3`` (float64); identity on the first frame, when too
-    few points survive, or when ``method`` is None / "none"."""
+    few points survive, or when ``method`` is None / "none".
+
+    ``device=k`` runs the frame preparation and the optical flow on GPU k (csrc/gmc_kernels.hip) and splits a step in two:
+    :meth:`begin` enqueues it (``model.track`` does so BEFORE the detector runs on the frame, so that both share the GPU),
+    :meth:`apply` collects it -- or enqueues and collects, when nobody called ``begin`` for that frame."""
 
     def __init__(self, method: Optional[str] = "sparseOptFlow", downscale: int = 2, device: Optional[int] = None):
-        self.device = device                   # None: Lucas-Kanade on the host; k: on GPU k (model.track passes the engine's device)
+        self.device = device                   # None: everything on the host; k: frame preparation + Lucas-Kanade on GPU k
         if method in ("none", "None"):
             method = None
         if method not in (None, "sparseOptFlow"):
@@ -365,20 +369,93 @@ class GMC:
         self.method, self.downscale = method, max(1, int(downscale))
         self.prev_frame: Optional[np.ndarray] = None
         self.prev_points: Optional[np.ndarray] = None
+        self._h = None                         # mi355_gmc object (device path), created by the first step
+        self._pending = None                   # (frame object, plane shape, points handed to Lucas-Kanade) of the enqueued step
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and h.value:
+            try:
+                from . import _lib
+                _lib.lib().mi355_gmc_destroy(h)
+            except Exception:
+                pass
 
     def reset(self) -> None:
         self.prev_frame = self.prev_points = None
 
+    # ---- device path ---------------------------------------------------------------------------------------------------------
+    def begin(self, raw_frame: np.ndarray) -> None:
+        """Enqueue this frame's step on the GPU (no-op on the host path); :meth:`apply` of the same frame object collects it."""
+        if self.method is None or self.device is None or raw_frame is None or raw_frame.ndim != 3 or self._pending is not None:
+            return
+        import ctypes as C
+        from . import _lib
+        lib = _lib.lib()
+        if self._h is None:
+            h = C.c_void_p()
+            rc = lib.mi355_gmc_create(int(self.device), C.byref(h))
+            if rc != 0:
+                raise RuntimeError(f"mi355_gmc_create: error {rc} on device {self.device}")
+            self._h = h
+        frame = np.ascontiguousarray(raw_frame, dtype=np.uint8)
+        h0, w0 = frame.shape[:2]
+        dh, dw = (h0 // self.downscale, w0 // self.downscale) if self.downscale > 1 else (h0, w0)
+        xt = yt = None
+        if self.downscale > 1:
+            xt, yt = _coeff_table(dw, w0), _coeff_table(dh, h0)
+        pts = None
+        if self.prev_frame is not None and self.prev_points is not None and self.prev_frame.shape == (dh, dw) and len(self.prev_points):
+            pts = np.ascontiguousarray(self.prev_points, dtype=np.float32).reshape(-1, 2)
+        rc = lib.mi355_gmc_step_begin(self._h, frame.ctypes.data, h0, w0, dh, dw, xt.ctypes.data if xt is not None else None,
+                                      yt.ctypes.data if yt is not None else None, float(QUALITY_LEVEL), pts.ctypes.data if pts is not None else None,
+                                      0 if pts is None else len(pts), LK_WIN, LK_LEVELS, LK_MAX_ITERS, float(LK_EPS), float(LK_MIN_EIG))
+        if rc != 0:
+            raise RuntimeError(f"mi355_gmc_step_begin: error {rc}")
+        self._pending = (raw_frame, (dh, dw), pts)
+
+    def _collect(self):
+        """-> (gray plane, corners, tracked points or None, status or None) of the enqueued step"""
+        from . import _lib
+        _, (dh, dw), pts = self._pending
+        self._pending = None
+        gray, eig, ok = np.empty((dh, dw), np.uint8), np.empty((dh, dw), np.float32), np.empty((dh, dw), np.uint8)
+        n = 0 if pts is None else len(pts)
+        nxt, status = np.zeros((n, 2), np.float32), np.zeros(n, np.uint8)
+        rc = _lib.lib().mi355_gmc_step_finish(self._h, gray.ctypes.data, eig.ctypes.data, ok.ctypes.data, nxt.ctypes.data if n else None,
+                                              status.ctypes.data if n else None)
+        if rc != 0:
+            raise RuntimeError(f"mi355_gmc_step_finish: error {rc}")
+        ys, xs = np.nonzero(ok)
+        order = np.argsort(-eig[ys, xs], kind="stable")[:MAX_CORNERS]
+        corners = np.stack([xs[order], ys[order]], axis=1).astype(np.float32).reshape(-1, 2)
+        return gray, corners, (nxt if n else None), (status.astype(bool) if n else None)
+
+    # ---- the step ------------------------------------------------------------------------------------------------------------
     def apply(self, raw_frame: np.ndarray, detections=None) -> np.ndarray:
         H = np.eye(2, 3)
         if self.method is None or raw_frame is None:
             return H
-        frame, points = prepare_frame(raw_frame, self.downscale, self.device)
-        if self.prev_frame is None or self.prev_points is None or self.prev_frame.shape != frame.shape:
-            self.prev_frame, self.prev_points = frame.copy(), points
-            return H
-        nxt, status = calc_optical_flow_pyr_lk(self.prev_frame, frame, self.prev_points, device=self.device)
-        p, q = self.prev_points[status], nxt[status]
+        if self.device is not None and raw_frame.ndim == 3:
+            if self._pending is not None and self._pending[0] is not raw_frame:
+                self._collect()                                      # a step enqueued for another frame: its results are stale
+                self.reset()
+            if self._pending is None:
+                self.begin(raw_frame)
+            tracked_from = self._pending[2]
+            frame, points, nxt, status = self._collect()
+            if tracked_from is None:
+                self.prev_frame, self.prev_points = frame, points
+                return H
+            prev_points = tracked_from
+        else:
+            frame, points = prepare_frame(raw_frame, self.downscale, None)
+            if self.prev_frame is None or self.prev_points is None or self.prev_frame.shape != frame.shape:
+                self.prev_frame, self.prev_points = frame.copy(), points
+                return H
+            prev_points = self.prev_points
+            nxt, status = calc_optical_flow_pyr_lk(self.prev_frame, frame, prev_points)
+        p, q = prev_points[status], nxt[status]
         if len(p) > 4:
             est, _ = estimate_affine_partial_2d(p, q)
             if est is not None:

@@ -236,6 +236,18 @@ int  mi355_gmc_pyr_lk_device(int device, const uint8_t* prev, const uint8_t* cur
  * border excluded); the caller orders the kept corners by strength.  Host buffers in and out.  0, -1 (bad argument), -2 (HIP error). */
 int  mi355_gmc_prepare_device(int device, const uint8_t* bgr, int height, int width, int oh, int ow, const int* xtab, const int* ytab,
                               double quality, uint8_t* gray_out, float* eig_out, uint8_t* ok_out);
+/* One motion-compensation step as two calls, so that it runs BESIDE the detector pass on a stream of its own: model.track() enqueues
+ * the step for a frame before the detector runs on it and collects it when the tracker asks for the warp.  The object keeps the
+ * previous frame's pyramid on the device.  step_begin = mi355_gmc_prepare_device of `bgr` plus, when n_prev > 0, Lucas-Kanade tracking
+ * of prev_pts from the previous step's plane into this one (that step must have prepared a plane of the same oh x ow); it returns at
+ * once and reads nothing of its arguments afterwards.  step_finish waits and fills gray / eig / ok [oh * ow] and, when the step had
+ * points, next_pts [n_prev][2] and status [n_prev].  One step may be pending per object.  0, -1 (bad argument / order), -2 (HIP). */
+typedef struct mi355_gmc mi355_gmc;
+int  mi355_gmc_create(int device, mi355_gmc** out);
+void mi355_gmc_destroy(mi355_gmc* g);
+int  mi355_gmc_step_begin(mi355_gmc* g, const uint8_t* bgr, int height, int width, int oh, int ow, const int* xtab, const int* ytab,
+                          double quality, const float* prev_pts, int n_prev, int win, int max_level, int max_iters, double eps, double min_eig);
+int  mi355_gmc_step_finish(mi355_gmc* g, uint8_t* gray_out, float* eig_out, uint8_t* ok_out, float* next_pts, uint8_t* status);
 /* The u8 stem: letterboxed BGR frames -> (x/255, RGB) -> conv k x k stride s (pad k/2, or 2 for k=6) + bias + SiLU. */
 int  mi355_op_stem(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias,
                    int cout, int k, int stride, float* y);

@@ -99,3 +99,50 @@ def test_tracker_on_the_device_keeps_the_ids_of_the_host_tracker():
             np.testing.assert_array_equal(a[:, 4], b[:, 4])                  # track ids
             np.testing.assert_allclose(a[:, :4], b[:, :4], atol=2e-2)        # boxes after the compensated Kalman update
     print(f"tracker update per frame: host {t_host / 12 * 1e3:.2f} ms, device {t_dev / 12 * 1e3:.2f} ms")
+
+
+def test_enqueued_steps_give_the_host_warps_and_survive_misuse():
+    """GMC.begin enqueues a frame's step, GMC.apply of the same frame object collects it: the warps of a panning clip equal the host
+    object's to 1e-3; a step enqueued for ANOTHER frame is discarded (the object starts over) instead of being taken for this one"""
+    h, w = 240, 320
+    big = ((_smooth_noise(h + 40, w + 200, seed=17, sigma=2.0).astype(np.int32) + _smooth_noise(h + 40, w + 200, seed=18, sigma=6.0)) // 2).astype(np.uint8)
+    frames = [np.repeat(big[10:10 + h, 7 * k:7 * k + w, None], 3, axis=2).copy() for k in range(8)]
+    host, dev = gmc.GMC(), gmc.GMC(device=0)
+    for k, f in enumerate(frames):
+        dev.begin(f)
+        a, b = host.apply(f), dev.apply(f)
+        np.testing.assert_allclose(b, a, atol=1e-3)
+        if k:
+            assert abs(a[0, 2] - (-7.0)) < 0.3 and abs(a[1, 2]) < 0.3           # the camera pans 7 px per frame
+    np.testing.assert_array_equal(dev.prev_frame, host.prev_frame)
+    np.testing.assert_array_equal(dev.prev_points, host.prev_points)
+    # misuse: a step is pending for frames[0], the tracker asks about frames[1]
+    dev.begin(frames[0])
+    w1 = dev.apply(frames[1])
+    np.testing.assert_array_equal(w1, np.eye(2, 3))                             # started over: first frame of a new sequence
+    np.testing.assert_allclose(dev.apply(frames[2]), dev_pair(frames[1], frames[2]), atol=1e-3)
+
+
+def dev_pair(f0, f1):
+    g = gmc.GMC()
+    g.apply(f0)
+    return g.apply(f1)
+
+
+def test_step_api_order_is_checked():
+    import ctypes as C
+    from cvsd_amd import _lib
+    lib = _lib.lib()
+    h = C.c_void_p()
+    assert lib.mi355_gmc_create(0, C.byref(h)) == 0
+    frame = np.zeros((64, 96, 3), np.uint8)
+    gray, eig, ok = np.empty((64, 96), np.uint8), np.empty((64, 96), np.float32), np.empty((64, 96), np.uint8)
+    assert lib.mi355_gmc_step_finish(h, gray.ctypes.data, eig.ctypes.data, ok.ctypes.data, None, None) == -1          # nothing pending
+    pts = np.ones((4, 2), np.float32)
+    args = (frame.ctypes.data, 64, 96, 64, 96, None, None, 0.01)
+    assert lib.mi355_gmc_step_begin(h, *args, pts.ctypes.data, 4, 21, 3, 30, 0.01, 1e-4) == -1                         # points, but no previous plane
+    assert lib.mi355_gmc_step_begin(h, *args, None, 0, 21, 3, 30, 0.01, 1e-4) == 0
+    assert lib.mi355_gmc_step_begin(h, *args, None, 0, 21, 3, 30, 0.01, 1e-4) == -1                                    # one step at a time
+    assert lib.mi355_gmc_step_finish(h, gray.ctypes.data, eig.ctypes.data, ok.ctypes.data, None, None) == 0
+    assert (gray == 0).all() and not ok.any()
+    lib.mi355_gmc_destroy(h)
