@@ -593,6 +593,32 @@ def track_pipeline(n_frames: int = 160) -> dict:
         for f in frames[8:]:
             model.track(f, persist=True, conf=0.1)
         out[key] = round((n_frames - 8) / (time.perf_counter() - t0), 1)
+
+    # the production form of the same loop (cvsd_amd/sweep.py): detection batched per clip, the tracker frame by frame, frame j + 1's
+    # motion-compensation step enqueued while frame j is associated
+    from cvsd_amd.sweep import process_clip
+
+    class Clip:
+        def __init__(self, fr):
+            self.fr, self.pos = fr, 0
+
+        def read(self):
+            if self.pos >= len(self.fr):
+                return False, None
+            self.pos += 1
+            return True, self.fr[self.pos - 1]
+
+        def get(self, prop):
+            return float(self.pos)
+
+        def release(self):
+            pass
+
+    big = YOLO(build_from_state_dict("yolov8n", sd), batch_chunk=64)
+    process_clip(big, Clip(frames[:64]), batch=64)
+    t0 = time.perf_counter()
+    process_clip(big, Clip(frames), batch=64)
+    out["sweep_batch64"] = round(n_frames / (time.perf_counter() - t0), 1)
     return out
 
 

@@ -45,15 +45,21 @@ def process_clip(model, cap, batch: int = 64, conf: float = 0.1, classes=(0,), *
     from .results import Boxes, clip_boxes
     from .tracker import BYTETracker
     import torch
-    tracker = BYTETracker()
+    tracker = BYTETracker(gmc_device=getattr(model, "device", None))     # motion compensation on the engine's GPU (csrc/gmc_kernels.hip)
     rows: List[List[float]] = []
     buf, nums = [], []
 
     def flush():
         if not buf:
             return
-        for n, frame, res in zip(nums, buf, model.predict(np.stack(buf), conf=conf, classes=list(classes), **predict_kw)):
-            tracks = tracker.update(res.boxes.data.numpy(), frame)    # every frame, empty ones too (frame_id / lost-track ageing)
+        tracker.gmc.begin(buf[0])                              # the first frame's motion-compensation step runs beside the detector
+        # a clip's last batch is filled up with copies of its last frame (their results are dropped): the engine plans -- and on
+        # first sight times -- its launches per batch size, and a sweep would otherwise meet every size from 1 to batch - 1
+        stack = np.stack(buf + [buf[-1]] * (batch - len(buf)))
+        results = model.predict(stack, conf=conf, classes=list(classes), **predict_kw)[:len(buf)]
+        for j, (n, frame, res) in enumerate(zip(nums, buf, results)):
+            # every frame, empty ones too (frame_id / lost-track ageing); frame j + 1's step is enqueued while frame j is associated
+            tracks = tracker.update(res.boxes.data.numpy(), frame, next_img=buf[j + 1] if j + 1 < len(buf) else None)
             if len(tracks):                                    # `if not boxes.is_track: return` otherwise (model.py:45)
                 b = Boxes(clip_boxes(torch.as_tensor(tracks[:, :-1], dtype=torch.float32), res.orig_shape), res.orig_shape)
                 for box in b:

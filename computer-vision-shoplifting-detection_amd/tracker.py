@@ -183,9 +183,11 @@ class BYTETracker:
             cost = 1 - (1 - cost) * np.array([d.score for d in dets])[None, :]
         return cost
 
-    def update(self, det: np.ndarray, img: Optional[np.ndarray] = None) -> np.ndarray:
+    def update(self, det: np.ndarray, img: Optional[np.ndarray] = None, next_img: Optional[np.ndarray] = None) -> np.ndarray:
         """``img``: the frame the detections come from (BGR uint8, as ``tracker.update(det, im0)`` receives it in
-        trackers/track.py); without it no motion compensation takes place (byte_tracker.py: ``if ... img is not None``)."""
+        trackers/track.py); without it no motion compensation takes place (byte_tracker.py: ``if ... img is not None``).
+        ``next_img``: the frame the NEXT call will bring, when the caller already holds it (a batched sweep): its motion-compensation
+        step is enqueued on the GPU as soon as this frame's has been collected, and runs beside this call's association."""
         self.frame_id += 1
         frame = self.frame_id
         det = np.asarray(det, dtype=np.float32).reshape(-1, 6)
@@ -209,6 +211,11 @@ class BYTETracker:
                 warp = self.gmc.apply(img)
             except Exception:                                   # byte_tracker.py bypasses errors of the gmc module the same way
                 warp = np.eye(2, 3)
+            if next_img is not None:
+                try:
+                    self.gmc.begin(next_img)                    # device path only; a no-op on the host
+                except Exception:
+                    pass
             if not np.array_equal(warp, np.eye(2, 3)):
                 R8 = np.kron(np.eye(4), warp[:2, :2])
                 for t in pool + tentative:

@@ -27,3 +27,36 @@ for label, dev in (("host GMC", None), ("GPU GMC", 0), ("no GMC", "off")):
         model.track(f, persist=True, classes=None, conf=0.1)
     dt = time.perf_counter() - t0
     print(f"{label:9s}: {(n - 5) / dt:8.1f} frames/s  ({dt / (n - 5) * 1e3:.2f} ms per frame: predict + tracker)")
+
+# the production form (cvsd_amd/sweep.py): batched detection, tracker frame by frame with the next frame's step enqueued ahead
+from cvsd_amd.sweep import process_clip
+
+
+class Clip:
+    def __init__(self, fr):
+        self.fr, self.pos = fr, 0
+
+    def read(self):
+        if self.pos >= len(self.fr):
+            return False, None
+        self.pos += 1
+        return True, self.fr[self.pos - 1]
+
+    def get(self, prop):
+        return float(self.pos)
+
+    def release(self):
+        pass
+
+
+big = YOLO(build_from_state_dict("yolov8n", sd), batch_chunk=64)
+for label, dev in (("GPU GMC", 0), ("host GMC", None)):
+    big.device = dev if dev is not None else big.device
+    if dev is None:
+        import cvsd_amd.sweep as S
+        orig = S.process_clip.__globals__["getattr"] if "getattr" in S.process_clip.__globals__ else None
+    process_clip(big, Clip(frames[:64]), batch=64)
+    t0 = time.perf_counter()
+    process_clip(big, Clip(frames), batch=64)
+    print(f"sweep batch 64, {label}: {n / (time.perf_counter() - t0):8.1f} frames/s")
+    break
