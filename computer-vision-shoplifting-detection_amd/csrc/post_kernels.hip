@@ -400,15 +400,17 @@ __device__ __forceinline__ bool iou_gt(const CandBox& i, const CandBox& j, float
     return ovr > thr;
 }
 
-__global__ __launch_bounds__(64 * NMS_WAVES) void nms_greedy_kernel(NmsArgs a, const int* cand_counts) {
+// WAVES = waves of the block running it (NMS_WAVES stand-alone; the sort kernel's 16 when it runs behind the sort in one launch)
+template <int WAVES>
+__device__ __forceinline__ void nms_greedy_body(const NmsArgs& a, const int b, const int n) {
+    constexpr int NMS_WAVES = WAVES;
     __shared__ float kx1[NMS_MAX_DET], ky1[NMS_MAX_DET], kx2[NMS_MAX_DET], ky2[NMS_MAX_DET], kar[NMS_MAX_DET];
     __shared__ int kan[NMS_MAX_DET];
     __shared__ unsigned long long survive[2][NMS_WAVES];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long* keys = a.keys + (size_t)b * a.Apow2;
     const float* pred = a.pred + (size_t)b * a.A * a.no;
     const float2* best = a.best + (size_t)b * a.A;
-    const int n = cand_counts[b];
     int nk = 0, it = 0;
     for (int base = 0; base < n && nk < a.max_det; base += 64, ++it) {
         const int j = base + lane;
@@ -501,6 +503,37 @@ __global__ __launch_bounds__(64 * NMS_WAVES) void nms_greedy_kernel(NmsArgs a, c
     }
 }
 
+__global__ __launch_bounds__(64 * NMS_WAVES) void nms_greedy_kernel(NmsArgs a, const int* cand_counts) {
+    nms_greedy_body<NMS_WAVES>(a, blockIdx.x, cand_counts[blockIdx.x]);
+}
+
+// Sort and greedy suppression of one image in ONE launch (small calls: a launch costs more than either kernel's work; the greedy
+// pass then runs on the sort's 16 waves, its share loop split 16 ways).  Same code, same order of operations, same rows.
+__global__ __launch_bounds__(NMS_SORT_THREADS) void nms_sort_greedy_kernel(NmsArgs a, int* cand_counts) {
+    __shared__ unsigned long long skeys[NMS_LDS_KEYS];
+    __shared__ int scount;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    unsigned long long* keys = a.keys + (size_t)b * a.Apow2;
+    int n = 0;
+    const int n2 = nms_collect(a, b, keys, &scount, tid, &n);
+    if (n2 > 1) {
+        if (n2 <= NMS_LDS_KEYS) {
+            for (int i = tid; i < n2; i += NMS_SORT_THREADS) skeys[i] = keys[i];
+            __syncthreads();
+            bitonic_sort(skeys, n2, tid, NMS_SORT_THREADS);
+            for (int i = tid; i < n; i += NMS_SORT_THREADS) keys[i] = skeys[i];
+        } else {
+            bitonic_sort_hybrid(keys, skeys, n2, tid);
+        }
+    }
+    const int nc = n < a.max_nms ? n : a.max_nms;
+    if (tid == 0) cand_counts[b] = nc;
+    __syncthreads();                                   // the block's sorted keys (global memory) are visible to all of its threads
+    nms_greedy_body<NMS_SORT_THREADS / 64>(a, b, nc);
+}
+
+static bool nms_fused_on() { static const bool on = !(getenv("MI355_NMS_FUSED") && atoi(getenv("MI355_NMS_FUSED")) == 0); return on; }
+
 const char* launch_nms(const NmsArgs& a, hipStream_t st) {
     if (a.max_det < 1 || a.max_det > NMS_MAX_DET) return "nms: max_det must be in [1, 1024]";
     // cand_counts lives in the tail of out_counts' allocation: out_counts[B .. 2B)
@@ -517,6 +550,11 @@ const char* launch_nms(const NmsArgs& a, hipStream_t st) {
                 hipLaunchKernelGGL(nms_global_step_kernel, dim3(a.B * bpi), dim3(NMS_SORT_THREADS), 0, st, a, sort_len, bpi, k, j);
             hipLaunchKernelGGL(nms_lds_steps_kernel, dim3(a.B * chunks), dim3(NMS_SORT_THREADS), 0, st, a, sort_len, chunks, k);
         }
+    } else if (a.B <= 16 && nms_fused_on()) {
+        // small calls: sort + greedy pass in one launch (a dependent launch costs 2.9 us + the kernel's ramp: DESIGN.md 3.5)
+        hipLaunchKernelGGL(nms_sort_greedy_kernel, dim3(a.B), dim3(NMS_SORT_THREADS), 0, st, a, cand_counts);
+        hipError_t e1 = hipGetLastError();
+        return e1 == hipSuccess ? nullptr : hipGetErrorString(e1);
     } else {
         hipLaunchKernelGGL(nms_sort_kernel, dim3(a.B), dim3(NMS_SORT_THREADS), 0, st, a, cand_counts);
     }
