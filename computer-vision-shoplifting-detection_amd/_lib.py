@@ -88,6 +88,9 @@ SIGNATURES = {
                                           C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "mi355_gmc_prepare_device": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double,
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_gmc_order_corners": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mi355_gmc_affine_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_ulonglong, C.c_void_p,
+                                           C.c_void_p]),
     "mi355_gmc_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "mi355_gmc_destroy": (None, [C.c_void_p]),
     "mi355_gmc_step_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,

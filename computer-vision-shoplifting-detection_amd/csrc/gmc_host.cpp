@@ -161,3 +161,92 @@ extern "C" int mi355_gmc_pyr_lk(const uint8_t* prev, const uint8_t* cur, int hei
     for (auto& t : th) t.join();
     return 0;
 }
+
+// ---- the two small host stages that follow the GPU step (same algorithms as cvsd_amd/gmc.py states them in numpy) ----------------
+
+// goodFeaturesToTrack's last step: the kept corners (ok != 0) strongest first, raster order among equals (numpy: nonzero + stable
+// argsort of -eig), at most max_corners; xy_out [max_corners][2] = (x, y) float32.  Returns the number written, or -1.
+extern "C" int mi355_gmc_order_corners(const float* eig, const uint8_t* ok, int height, int width, int max_corners, float* xy_out) {
+    if (!eig || !ok || height <= 0 || width <= 0 || max_corners < 0 || (max_corners > 0 && !xy_out)) return -1;
+    std::vector<int> idx;
+    const int n = height * width;
+    for (int i = 0; i < n; ++i) if (ok[i]) idx.push_back(i);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return eig[a] > eig[b]; });
+    const int m = std::min((int)idx.size(), max_corners);
+    for (int k = 0; k < m; ++k) { xy_out[2 * k] = (float)(idx[k] % width); xy_out[2 * k + 1] = (float)(idx[k] / width); }
+    return m;
+}
+
+namespace {
+// least-squares similarity [[a, -b, tx], [b, a, ty]] mapping p -> q over the selected pairs (exact for two pairs)
+void similarity_fit(const double* src, const double* dst, const std::vector<int>& sel, double* H) {
+    double pmx = 0, pmy = 0, qmx = 0, qmy = 0;
+    for (int i : sel) { pmx += src[2 * i]; pmy += src[2 * i + 1]; qmx += dst[2 * i]; qmy += dst[2 * i + 1]; }
+    const double inv = 1.0 / (double)sel.size();
+    pmx *= inv; pmy *= inv; qmx *= inv; qmy *= inv;
+    double den = 0, sa = 0, sb = 0;
+    for (int i : sel) {
+        const double px = src[2 * i] - pmx, py = src[2 * i + 1] - pmy, qx = dst[2 * i] - qmx, qy = dst[2 * i + 1] - qmy;
+        den += px * px + py * py; sa += px * qx + py * qy; sb += px * qy - py * qx;
+    }
+    if (den <= 0) { H[0] = 1; H[1] = 0; H[2] = qmx - pmx; H[3] = 0; H[4] = 1; H[5] = qmy - pmy; return; }
+    const double a = sa / den, b = sb / den;
+    H[0] = a; H[1] = -b; H[2] = qmx - (a * pmx - b * pmy);
+    H[3] = b; H[4] = a;  H[5] = qmy - (b * pmx + a * pmy);
+}
+inline bool same_point(const double* a, const double* b) {       // np.allclose on a 2-vector (rtol 1e-5, atol 1e-8)
+    return std::fabs(a[0] - b[0]) <= 1e-8 + 1e-5 * std::fabs(b[0]) && std::fabs(a[1] - b[1]) <= 1e-8 + 1e-5 * std::fabs(b[1]);
+}
+}  // namespace
+
+// cv2.estimateAffinePartial2D(src, dst, RANSAC): 2-point similarity hypotheses, reprojection threshold, adaptive stopping at the asked
+// confidence, least-squares refit on the consensus set (gmc.estimate_affine_partial_2d states the same in numpy; the draws come from a
+// generator of this routine's own -- splitmix64 seeded with `seed` -- so on data with outliers the two may stop on different, equally
+// valid consensus sets).  src / dst: float64 [n][2]; H_out: 6 doubles (row-major 2 x 3); inliers_out: n bytes or NULL.
+// Returns 1 when a transform was found, 0 when not (H_out untouched), -1 on bad arguments.
+extern "C" int mi355_gmc_affine_partial(const double* src, const double* dst, int n, double threshold, double confidence, int max_iters,
+                                        unsigned long long seed, double* H_out, uint8_t* inliers_out) {
+    if (n < 0 || (n > 0 && (!src || !dst)) || !H_out || max_iters < 0) return -1;
+    if (inliers_out) std::memset(inliers_out, 0, (size_t)n);
+    if (n < 2) return 0;
+    unsigned long long state = seed + 0x9E3779B97F4A7C15ull;
+    auto next = [&]() {
+        unsigned long long z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    std::vector<uint8_t> best((size_t)n, 0), mask((size_t)n, 0);
+    int best_count = 0;
+    const double thr2 = threshold * threshold;
+    int iters = max_iters;
+    std::vector<int> pair(2);
+    for (int it = 0; it < iters;) {
+        ++it;
+        const int i = (int)(next() % (unsigned long long)n);
+        int j = (int)(next() % (unsigned long long)(n - 1));
+        if (j >= i) ++j;
+        if (same_point(src + 2 * i, src + 2 * j) || same_point(dst + 2 * i, dst + 2 * j)) continue;
+        pair[0] = i; pair[1] = j;
+        double H[6];
+        similarity_fit(src, dst, pair, H);
+        int cnt = 0;
+        for (int k = 0; k < n; ++k) {
+            const double ex = H[0] * src[2 * k] + H[1] * src[2 * k + 1] + H[2] - dst[2 * k];
+            const double ey = H[3] * src[2 * k] + H[4] * src[2 * k + 1] + H[5] - dst[2 * k + 1];
+            mask[k] = (ex * ex + ey * ey) <= thr2;
+            cnt += mask[k];
+        }
+        if (cnt > std::max(best_count, 1)) {
+            best.swap(mask); best_count = cnt;
+            const double w = (double)cnt / (double)n;
+            const double denom = std::log(std::max(1.0 - w * w, 1e-12));
+            if (denom < 0) iters = std::min(iters, (int)std::ceil(std::log(1.0 - confidence) / denom)); else iters = it;
+        }
+    }
+    if (best_count < 2) return 0;
+    std::vector<int> sel;
+    for (int k = 0; k < n; ++k) if (best[k]) sel.push_back(k);
+    similarity_fit(src, dst, sel, H_out);
+    if (inliers_out) std::memcpy(inliers_out, best.data(), (size_t)n);
+    return 1;
+}

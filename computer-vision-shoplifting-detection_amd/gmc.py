@@ -147,9 +147,7 @@ def prepare_frame(raw_frame: np.ndarray, downscale: int = 2, device: Optional[in
         raise RuntimeError(f"mi355_gmc_prepare_device: HIP error on device {device}")
     if rc != 0:
         raise ValueError("mi355_gmc_prepare_device: bad argument")
-    ys, xs = np.nonzero(ok)
-    order = np.argsort(-eig[ys, xs], kind="stable")[:max_corners]
-    return gray, np.stack([xs[order], ys[order]], axis=1).astype(np.float32).reshape(-1, 2)
+    return gray, order_corners(eig, ok, max_corners)
 
 
 # ------------------------------------------------------------------------------------------------- pyramidal Lucas-Kanade
@@ -351,6 +349,36 @@ def estimate_affine_partial_2d(src: np.ndarray, dst: np.ndarray, threshold: floa
     return H, best_mask
 
 
+def order_corners(eig: np.ndarray, ok: np.ndarray, max_corners: int = MAX_CORNERS) -> np.ndarray:
+    """goodFeaturesToTrack's last step on a corner map: kept corners strongest first, raster order among equals -> float32 [n, 2]
+    (host C++, csrc/gmc_host.cpp; the numpy form is the tail of :func:`good_features_to_track`)."""
+    from . import _lib
+    eig = np.ascontiguousarray(eig, dtype=np.float32)
+    ok = np.ascontiguousarray(ok, dtype=np.uint8)
+    out = np.empty((max(1, max_corners), 2), np.float32)
+    n = _lib.lib().mi355_gmc_order_corners(eig.ctypes.data, ok.ctypes.data, eig.shape[0], eig.shape[1], int(max_corners), out.ctypes.data)
+    if n < 0:
+        raise ValueError("mi355_gmc_order_corners: bad argument")
+    return out[:n].copy()
+
+
+def estimate_affine_partial_2d_host(src: np.ndarray, dst: np.ndarray, threshold: float = RANSAC_THRESHOLD, confidence: float = RANSAC_CONFIDENCE,
+                                    max_iters: int = RANSAC_MAX_ITERS, seed: int = 0) -> Tuple[Optional[np.ndarray], np.ndarray]:
+    """:func:`estimate_affine_partial_2d` as host C++ loops (csrc/gmc_host.cpp: what the tracker runs, 10x less time per frame);
+    same algorithm, draws from that routine's own seeded generator."""
+    from . import _lib
+    src = np.ascontiguousarray(src, dtype=np.float64).reshape(-1, 2)
+    dst = np.ascontiguousarray(dst, dtype=np.float64).reshape(-1, 2)
+    n = len(src)
+    H = np.zeros((2, 3), np.float64)
+    mask = np.zeros(n, np.uint8)
+    rc = _lib.lib().mi355_gmc_affine_partial(src.ctypes.data, dst.ctypes.data, n, float(threshold), float(confidence), int(max_iters), int(seed),
+                                             H.ctypes.data, mask.ctypes.data)
+    if rc < 0:
+        raise ValueError("mi355_gmc_affine_partial: bad argument")
+    return (H if rc == 1 else None), mask.astype(bool)
+
+
 # ------------------------------------------------------------------------------------------------- the GMC object
 class GMC:
     """``GMC(method="sparseOptFlow", downscale=2).apply(frame_bgr) -> 2x3`` (float64); identity on the first frame, when too
@@ -426,10 +454,7 @@ class GMC:
                                               status.ctypes.data if n else None)
         if rc != 0:
             raise RuntimeError(f"mi355_gmc_step_finish: error {rc}")
-        ys, xs = np.nonzero(ok)
-        order = np.argsort(-eig[ys, xs], kind="stable")[:MAX_CORNERS]
-        corners = np.stack([xs[order], ys[order]], axis=1).astype(np.float32).reshape(-1, 2)
-        return gray, corners, (nxt if n else None), (status.astype(bool) if n else None)
+        return gray, order_corners(eig, ok, MAX_CORNERS), (nxt if n else None), (status.astype(bool) if n else None)
 
     # ---- the step ------------------------------------------------------------------------------------------------------------
     def apply(self, raw_frame: np.ndarray, detections=None) -> np.ndarray:
@@ -457,7 +482,7 @@ class GMC:
             nxt, status = calc_optical_flow_pyr_lk(self.prev_frame, frame, prev_points)
         p, q = prev_points[status], nxt[status]
         if len(p) > 4:
-            est, _ = estimate_affine_partial_2d(p, q)
+            est, _ = estimate_affine_partial_2d_host(p, q)
             if est is not None:
                 H = est
                 H[0, 2] *= self.downscale

@@ -39,14 +39,16 @@ class PoseLiftWriter:
 
 
 def video_to_poselift(model, frames: Iterable[np.ndarray], out_path: Optional[str] = None, conf: float = 0.25,
-                      batch: int = 64, first_frame: int = 0, **predict_kw) -> Dict[int, Dict[int, list]]:
+                      batch: int = 64, first_frame: int = 0, gmc_device: Optional[int] = None, **predict_kw) -> Dict[int, Dict[int, list]]:
     """Run a pose model over the frames of ONE video and build its PoseLift dict (optionally pickled to ``out_path``).
-    Detection runs in batches on the GPU; tracking is sequential on the host, in frame order."""
+    Detection runs in batches on the GPU; tracking is sequential on the host, in frame order.  ``gmc_device``: GPU that runs the
+    tracker's motion compensation (``model.device`` for speed); the default keeps it on the host, whose track boxes are the ones
+    the committed fixture holds bit for bit (the GPU routine agrees to 1e-3 px, not to the last bit)."""
     from .results import clip_boxes
     from .tracker import BYTETracker
     if getattr(model, "task", "pose") != "pose":
         raise ValueError("video_to_poselift needs a pose model (e.g. yolov8n-pose)")
-    tracker = BYTETracker()
+    tracker = BYTETracker(gmc_device=gmc_device)
     w = PoseLiftWriter()
     buf, n = [], first_frame
 

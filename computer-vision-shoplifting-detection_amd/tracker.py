@@ -209,13 +209,12 @@ class BYTETracker:
             from .gmc import warp_kalman
             try:
                 warp = self.gmc.apply(img)
-            except Exception:                                   # byte_tracker.py bypasses errors of the gmc module the same way
+            except (np.linalg.LinAlgError, ValueError, FloatingPointError, ZeroDivisionError):
+                # byte_tracker.py bypasses errors of the gmc module the same way (degenerate point sets); a RuntimeError of the
+                # device path (HIP error, library without the kernels) is NOT one of them and surfaces
                 warp = np.eye(2, 3)
             if next_img is not None:
-                try:
-                    self.gmc.begin(next_img)                    # device path only; a no-op on the host
-                except Exception:
-                    pass
+                self.gmc.begin(next_img)                        # device path only; a no-op on the host
             if not np.array_equal(warp, np.eye(2, 3)):
                 R8 = np.kron(np.eye(4), warp[:2, :2])
                 for t in pool + tentative:

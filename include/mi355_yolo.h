@@ -242,6 +242,13 @@ int  mi355_gmc_prepare_device(int device, const uint8_t* bgr, int height, int wi
  * of prev_pts from the previous step's plane into this one (that step must have prepared a plane of the same oh x ow); it returns at
  * once and reads nothing of its arguments afterwards.  step_finish waits and fills gray / eig / ok [oh * ow] and, when the step had
  * points, next_pts [n_prev][2] and status [n_prev].  One step may be pending per object.  0, -1 (bad argument / order), -2 (HIP). */
+/* The two small host stages behind the GPU step, as gmc.py states them in numpy: goodFeaturesToTrack's ordering of the kept corners
+ * (strongest first, raster order among equals, at most max_corners; returns the count written to xy_out [max_corners][2]) and
+ * cv2.estimateAffinePartial2D (RANSAC over 2-point similarities + refit; src / dst float64 [n][2]; returns 1 and fills H_out [6] and
+ * inliers_out [n] (may be NULL), 0 when no transform was found, -1 on bad arguments; draws from its own seeded generator). */
+int  mi355_gmc_order_corners(const float* eig, const uint8_t* ok, int height, int width, int max_corners, float* xy_out);
+int  mi355_gmc_affine_partial(const double* src, const double* dst, int n, double threshold, double confidence, int max_iters,
+                              unsigned long long seed, double* H_out, uint8_t* inliers_out);
 typedef struct mi355_gmc mi355_gmc;
 int  mi355_gmc_create(int device, mi355_gmc** out);
 void mi355_gmc_destroy(mi355_gmc* g);

@@ -214,3 +214,35 @@ def test_host_cpp_lucas_kanade_is_the_numpy_statement_of_the_algorithm():
     both = sa & sb
     assert both.sum() > 100 and np.abs(a[both] - b[both]).max() < 1e-3
     assert gmc.calc_optical_flow_pyr_lk(prev, cur, np.zeros((0, 2), np.float32))[0].shape == (0, 2)
+
+
+def test_host_cpp_corner_ordering_and_ransac_are_the_numpy_statements():
+    """csrc/gmc_host.cpp: the ordering of the kept corners (ties in raster order) and the RANSAC similarity, against the numpy forms"""
+    rng = np.random.default_rng(4)
+    eig = rng.integers(0, 12, size=(37, 53)).astype(np.float32) * np.float32(0.25)          # many ties
+    ok = (rng.random((37, 53)) < 0.3).astype(np.uint8)
+    ys, xs = np.nonzero(ok)
+    order = np.argsort(-eig[ys, xs], kind="stable")
+    want = np.stack([xs[order], ys[order]], axis=1).astype(np.float32)
+    np.testing.assert_array_equal(gmc.order_corners(eig, ok, 10 ** 6), want)
+    np.testing.assert_array_equal(gmc.order_corners(eig, ok, 50), want[:50])
+    assert gmc.order_corners(eig, np.zeros_like(ok), 50).shape == (0, 2)
+    # RANSAC: clean points -> the exact similarity; a quarter of planted outliers -> the planted inlier set and the refit on it
+    ang, sc = 0.03, 1.02
+    A = np.array([[sc * np.cos(ang), -sc * np.sin(ang), 4.5], [sc * np.sin(ang), sc * np.cos(ang), -2.25]])
+    p = rng.uniform(0, 300, size=(200, 2))
+    q = p @ A[:, :2].T + A[:, 2]
+    H, m = gmc.estimate_affine_partial_2d_host(p, q)
+    assert m.all() and np.abs(H - A).max() < 1e-9
+    q2 = q.copy()
+    bad = rng.choice(200, 50, replace=False)
+    q2[bad] += rng.uniform(20, 60, size=(50, 2)) * rng.choice([-1, 1], size=(50, 2))
+    H2, m2 = gmc.estimate_affine_partial_2d_host(p, q2)
+    Hn, mn = gmc.estimate_affine_partial_2d(p, q2)
+    good = np.ones(200, bool); good[bad] = False
+    np.testing.assert_array_equal(m2, good)
+    np.testing.assert_array_equal(mn, good)
+    assert np.abs(H2 - Hn).max() < 1e-9 and np.abs(H2 - A).max() < 1e-9
+    assert gmc.estimate_affine_partial_2d_host(p[:1], q[:1])[0] is None
+    # all points identical: no hypothesis survives
+    assert gmc.estimate_affine_partial_2d_host(np.zeros((10, 2)), np.zeros((10, 2)))[0] is None

@@ -229,6 +229,21 @@ def test_config5_yolov8m_1280_half():
         assert err[2] <= 4.0 * noise[2] + 1e-4, (group, "max", err, noise)
 
 
+def test_config5_at_its_stated_batch_of_two_equals_frame_by_frame():
+    """BASELINE config 5 as stated: YOLOv8m, 1280x1280, half, TWO frames per GPU -- the batch-2 launch plans (other tiles, fused
+    pairs, merged head convs) give the rows of the one-frame calls whose head tensor the test above bounds, bit for bit."""
+    from tools import synth
+    ckpt = synth.synthetic_checkpoint("yolov8m", seed=0)
+    m = _half_model("yolov8m", ckpt, batch_chunk=2)
+    frames = synth.synthetic_frames(2, 1280, 1280, seed=3)
+    both = m.predict(frames, conf=0.25, imgsz=1280)
+    for i in range(2):
+        one = m.predict(frames[i], conf=0.25, imgsz=1280)[0]
+        np.testing.assert_array_equal(both[i].anchor_idx, one.anchor_idx)
+        np.testing.assert_array_equal(both[i].boxes.data.numpy(), one.boxes.data.numpy())
+    assert sum(len(r.anchor_idx) for r in both) > 0
+
+
 def test_reference_call_sites_with_half(v8n_pose):
     """the reference's own calls on the half engine: .track(frame, persist=True, classes=[0]) (model.py:38) and
     model(frame).keypoints on a UCF-Crime-shaped frame (resize + letterbox path)"""
