@@ -23,7 +23,7 @@
 namespace {
 
 constexpr int kMaxLevels = 8;          // pyramid levels held (level 0 = the frame)
-constexpr int kMaxPer = 16;            // window pixels per lane: win <= 31 (961 = 15.02 * 64)
+constexpr int kMaxPer = 7;             // window pixels per lane: win <= 21 (441 = 6.9 * 64; OpenCV's and Ultralytics' default window)
 
 __device__ __forceinline__ int reflect101(int i, int n) {          // BORDER_REFLECT_101, any distance (as the host code)
     if (n == 1) return 0;
@@ -102,28 +102,33 @@ __device__ __forceinline__ void patch(const uint8_t* img, int h, int w, double p
 }
 
 // The iteration reads the current frame through a per-wavefront LDS copy of the neighbourhood it is walking in: (win + 1 + 2 M)^2
-// reflect-padded intensities as doubles, refilled only when the window's corner leaves the margin M.  The values are those
+// reflect-padded intensities (bytes), refilled only when the window's corner leaves the margin M.  The values are those
 // plane_at<0> returns, so the arithmetic -- and every bit of the result -- is that of reading global memory each time; what goes
 // away is four byte loads with reflected addresses per window pixel per iteration (three quarters of the kernel's instructions).
 constexpr int kMargin = 3;
-constexpr int kRegMax = 31 + 1 + 2 * kMargin;          // region side for the largest window
+constexpr int kRegMax = 21 + 1 + 2 * kMargin;          // region side for the largest window
 
-__device__ __forceinline__ void fill_region(const uint8_t* img, int h, int w, int ry, int rx, int R, int lane, double* reg) {
+__device__ __forceinline__ void fill_region(const uint8_t* img, int h, int w, int ry, int rx, int R, int lane, uint8_t* reg) {
     for (int k = lane; k < R * R; k += 64) {
         const int r = k / R, c = k - r * R;
-        reg[k] = plane_at<0>(img, h, w, ry + r, rx + c);
+        reg[k] = img[(size_t)reflect101(ry + r, h) * w + reflect101(rx + c, w)];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
-// one wavefront per point; block = 4 wavefronts
-__global__ __launch_bounds__(256) void lk_kernel(LkArgs a) {
-    __shared__ double region[4][kRegMax * kRegMax];
+// one wavefront per point; block = kLkWaves wavefronts (4: eight or sixteen points per block, meant to leave more CUs to the detector
+// pass this kernel runs beside, measured equal / 5-10 % slower on the track loop -- tools/lk_waves_ab.sh)
+#ifndef MI355_LK_WAVES
+#define MI355_LK_WAVES 4
+#endif
+constexpr int kLkWaves = MI355_LK_WAVES;
+__global__ __launch_bounds__(64 * kLkWaves) void lk_kernel(LkArgs a) {
+    __shared__ uint8_t region[kLkWaves][(kRegMax * kRegMax + 15) & ~15];
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = blockIdx.x * kLkWaves + (threadIdx.x >> 6);
     if (i >= a.n) return;
-    double* reg = region[threadIdx.x >> 6];
+    uint8_t* reg = region[threadIdx.x >> 6];
     const int win = a.win, half = win / 2, W2 = win * win;
     const int per = (W2 + 63) / 64;
     const int R = win + 1 + 2 * kMargin;
@@ -180,15 +185,15 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a) {
                 fill_region(a.cur[l], h, w, ry, rx, R, lane, reg);
                 have_region = true;
             }
-            const double* r0 = reg + (iy - ry) * R + (ix - rx);
+            const uint8_t* r0 = reg + (iy - ry) * R + (ix - rx);
             double b1 = 0, b2 = 0;
 #pragma unroll
             for (int j = 0; j < kMaxPer; ++j) {
                 if (j >= per) break;
                 double Jv = 0.0;                                 // lanes past the window hold zeros in I / Ix / Iy too
                 if (koff[j] >= 0) {
-                    const double* q = r0 + koff[j];
-                    Jv = w00 * q[0] + w01 * q[1] + w10 * q[R] + w11 * q[R + 1];
+                    const uint8_t* q = r0 + koff[j];
+                    Jv = w00 * (double)q[0] + w01 * (double)q[1] + w10 * (double)q[R] + w11 * (double)q[R + 1];
                 }
                 const double d = (Jv - I[j]) * 32.0;
                 b1 += d * Ix[j]; b2 += d * Iy[j];
@@ -311,7 +316,7 @@ GmcCtx g_ctx[16];
 // Same contract as mi355_gmc_pyr_lk (gmc_host.cpp) with the work done on GPU `device`: 0 = ok, -1 = bad argument, -2 = HIP error.
 extern "C" int mi355_gmc_pyr_lk_device(int device, const uint8_t* prev, const uint8_t* cur, int height, int width, const float* pts, int n,
                                        int win, int max_level, int max_iters, double eps, double min_eig, float* next_pts, uint8_t* status) {
-    if (!prev || !cur || height <= 0 || width <= 0 || n < 0 || (n > 0 && (!pts || !next_pts || !status)) || win < 3 || !(win & 1) || win > 31 ||
+    if (!prev || !cur || height <= 0 || width <= 0 || n < 0 || (n > 0 && (!pts || !next_pts || !status)) || win < 3 || !(win & 1) || win > 21 ||
         device < 0 || device >= 16 || max_level < 0)
         return -1;
     if (n == 0) return 0;
@@ -367,7 +372,7 @@ extern "C" int mi355_gmc_pyr_lk_device(int device, const uint8_t* prev, const ui
     a.top = levels - 1; a.n = n; a.win = win; a.max_iters = max_iters; a.width = width; a.height = height;
     a.eps2 = eps * eps; a.min_eig = min_eig;
     a.pts = c.d_pts; a.next = c.d_next; a.status = c.d_status;
-    hipLaunchKernelGGL(lk_kernel, dim3((n + 3) / 4), dim3(256), 0, c.stream, a);
+    hipLaunchKernelGGL(lk_kernel, dim3((n + kLkWaves - 1) / kLkWaves), dim3(64 * kLkWaves), 0, c.stream, a);
     GCHK(hipGetLastError());
     GCHK(hipMemcpyAsync(h_next, c.d_next, (size_t)n * 8, hipMemcpyDeviceToHost, c.stream));
     GCHK(hipMemcpyAsync(h_status, c.d_status, (size_t)n, hipMemcpyDeviceToHost, c.stream));
@@ -478,7 +483,7 @@ extern "C" void mi355_gmc_destroy(mi355_gmc* g) {
 extern "C" int mi355_gmc_step_begin(mi355_gmc* g, const uint8_t* bgr, int height, int width, int oh, int ow, const int* xtab, const int* ytab,
                                     double quality, const float* prev_pts, int n_prev, int win, int max_level, int max_iters, double eps,
                                     double min_eig) {
-    if (!g || !bgr || height <= 0 || width <= 0 || oh <= 0 || ow <= 0 || n_prev < 0 || (n_prev > 0 && !prev_pts) || win < 3 || !(win & 1) || win > 31 ||
+    if (!g || !bgr || height <= 0 || width <= 0 || oh <= 0 || ow <= 0 || n_prev < 0 || (n_prev > 0 && !prev_pts) || win < 3 || !(win & 1) || win > 21 ||
         max_level < 0)
         return -1;
     const int resize = !(oh == height && ow == width);
@@ -560,7 +565,7 @@ extern "C" int mi355_gmc_step_begin(mi355_gmc* g, const uint8_t* bgr, int height
         a.top = levels - 1; a.n = n_prev; a.win = win; a.max_iters = max_iters; a.width = ow; a.height = oh;
         a.eps2 = eps * eps; a.min_eig = min_eig;
         a.pts = g->d_pts; a.next = g->d_next; a.status = g->d_status;
-        hipLaunchKernelGGL(lk_kernel, dim3((n_prev + 3) / 4), dim3(256), 0, g->stream, a);
+        hipLaunchKernelGGL(lk_kernel, dim3((n_prev + kLkWaves - 1) / kLkWaves), dim3(64 * kLkWaves), 0, g->stream, a);
         GCHK(hipMemcpyAsync(hp + g->o_hnext, g->d_next, (size_t)n_prev * 8, hipMemcpyDeviceToHost, g->stream));
         GCHK(hipMemcpyAsync(hp + g->o_hstatus, g->d_status, (size_t)n_prev, hipMemcpyDeviceToHost, g->stream));
     }

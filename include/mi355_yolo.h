@@ -226,7 +226,7 @@ int  mi355_gmc_pyr_lk(const uint8_t* prev, const uint8_t* cur, int height, int w
 /* The same on GPU `device` (csrc/gmc_kernels.hip: one wavefront per point, float64, pyramids built on the GPU; host buffers in and
  * out).  On the host the 1000-corner budget costs 10-27 ms per frame -- thirty times the detector pass -- so model.track() hands
  * its tracker the engine's device.  Results agree with the host routine to rounding (window sums are associated differently).
- * win <= 31.  Returns 0, -1 (bad argument) or -2 (HIP error). */
+ * win <= 21 (the default window).  Returns 0, -1 (bad argument) or -2 (HIP error). */
 int  mi355_gmc_pyr_lk_device(int device, const uint8_t* prev, const uint8_t* cur, int height, int width, const float* pts, int n, int win,
                              int max_level, int max_iters, double eps, double min_eig, float* next_pts, uint8_t* status);
 /* Frame preparation of the same motion compensation on GPU `device`: BGR frame -> gray plane of oh x ow (cv2.cvtColor(BGR2GRAY) +

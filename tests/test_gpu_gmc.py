@@ -74,7 +74,7 @@ def test_device_routine_rejects_bad_arguments_and_takes_empty_input():
     prev, cur = _pair()
     assert gmc.calc_optical_flow_pyr_lk(prev, cur, np.zeros((0, 2), np.float32), device=0)[0].shape == (0, 2)
     with pytest.raises(ValueError):
-        gmc.calc_optical_flow_pyr_lk(prev, cur, np.ones((3, 2), np.float32), win=33, device=0)      # windows above 31 x 31: host only
+        gmc.calc_optical_flow_pyr_lk(prev, cur, np.ones((3, 2), np.float32), win=23, device=0)      # windows above 21 x 21: host only
     with pytest.raises(ValueError):
         gmc.calc_optical_flow_pyr_lk(prev, cur, np.ones((3, 2), np.float32), device=99)
 
