@@ -146,3 +146,32 @@ def test_step_api_order_is_checked():
     assert lib.mi355_gmc_step_finish(h, gray.ctypes.data, eig.ctypes.data, ok.ctypes.data, None, None) == 0
     assert (gray == 0).all() and not ok.any()
     lib.mi355_gmc_destroy(h)
+
+
+@pytest.mark.parametrize("shape", [(24, 40), (50, 44), (1080, 1920)])
+def test_device_steps_on_tiny_and_large_frames_follow_the_host(shape):
+    """frames smaller than the 21 x 21 window (no pyramid level fits, few or no corners) and a 1080p frame (buffer sizing): the GPU
+    object returns the host object's warps"""
+    h, w = shape
+    g = _smooth_noise(h + 12, w + 12, seed=29, sigma=1.5)
+    frames = [np.repeat(g[4 + k:4 + k + h, 3 * (k % 3):3 * (k % 3) + w, None], 3, axis=2).copy() for k in range(3)]
+    host, dev = gmc.GMC(), gmc.GMC(device=0)
+    for f in frames:
+        a, b = host.apply(f), dev.apply(f)
+        np.testing.assert_allclose(b, a, atol=2e-3)
+    np.testing.assert_array_equal(dev.prev_frame, host.prev_frame)
+    np.testing.assert_array_equal(dev.prev_points, host.prev_points)
+
+
+def test_frame_size_change_restarts_the_sequence():
+    g = _smooth_noise(300, 400, seed=31, sigma=2.0)
+    a = np.repeat(g[:240, :320, None], 3, axis=2).copy()
+    b = np.repeat(g[:200, :300, None], 3, axis=2).copy()
+    dev = gmc.GMC(device=0)
+    dev.apply(a)
+    np.testing.assert_array_equal(dev.apply(b), np.eye(2, 3))          # another plane size: first frame of a new sequence
+    assert dev.prev_frame.shape == (100, 150)
+    host = gmc.GMC()
+    host.apply(b)
+    b2 = np.repeat(g[2:202, 3:303, None], 3, axis=2).copy()
+    np.testing.assert_allclose(dev.apply(b2), host.apply(b2), atol=2e-3)
