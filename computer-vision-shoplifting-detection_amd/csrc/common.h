@@ -181,6 +181,22 @@ const char* launch_nms(const NmsArgs& a, hipStream_t st);
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 #if defined(__HIPCC__)
+// 16-byte buffer store whose data registers may be rewritten right after it.  gfx950 (measured, tools/dbg_conv_plans.py): the next vector
+// instruction may NOT overwrite the VGPRs a buffer_store_dwordx4 takes its data from, also when the store takes its offset from an SGPR
+// -- the one form for which the compiler's hazard recogniser inserts no wait state (its rule for "VMEM store of more than 8 bytes, data
+// registers overwritten" exempts stores with an SGPR offset).  A head's final conv (no activation: bias add of the next tile two
+// instructions behind the store) then stored the NEXT tile's bits / zeros in dword 0 of pixel lanes 12-15, in 1-20 % of the launches
+// of some plans; one wait state was enough in 8 of 8 runs, two are inserted.  Round 3's "zeroed lanes 12-15" of the streaming
+// pointwise member of a grouped launch was this.
+typedef unsigned mi355_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buffer_store_b128(mi355_u32x4 v, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, soffset, 0);
+    asm volatile("s_nop 1" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+#endif
+
+#if defined(__HIPCC__)
 // XCD-aware work order for the (tile, cout group) grids of the conv kernels.  Workgroups are dealt round-robin over the 8 XCDs
 // in dispatch order (x fastest, then y), so the blocks that share one XCD's L2 are b, b + 8, ...  Each of those eight
 // sequences is given a CONTIGUOUS run of the logical order "tile-major, cout group innermost": the groups of one input tile

@@ -195,7 +195,7 @@ __device__ __forceinline__ void store_tiles_f16_v2(const OutF16& o, f32x4 (&acc)
                 if (t >= n_full) { ragged(acc[ct][pt], bias4[ct], t * 16 + 4 * (int)g, dvo, rvo, so); continue; }
                 f32x4 v = bias_act4(acc[ct][pt], bias4[ct], o.act);
                 if (o.has_res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(o.rrs, (int)rvo, so, 0));
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o.drs, (int)dvo, so, 0);
+                buffer_store_b128(__builtin_bit_cast(u32x4, v), o.drs, (int)dvo, so);
             }
             __builtin_amdgcn_sched_barrier(0);      // one pixel tile at a time: the accumulators leave their registers tile by tile
         }
@@ -221,7 +221,7 @@ __device__ __forceinline__ void store_tiles_f16_v2(const OutF16& o, f32x4 (&acc)
                 f16x8 h;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { h[i] = (_Float16)w0[i]; h[4 + i] = (_Float16)w1[i]; }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), o.drs, (int)dvo, (t >> 1) * 64, 0);
+                buffer_store_b128(__builtin_bit_cast(u32x4, h), o.drs, (int)dvo, (t >> 1) * 64);
             }
             __builtin_amdgcn_sched_barrier(0);
         }

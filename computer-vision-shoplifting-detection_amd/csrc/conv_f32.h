@@ -85,7 +85,7 @@ __device__ __forceinline__ void conv_epilogue(const KA& a, f32x4 (&acc)[CT][PT],
             f32x4 v = acc[ct][pt];
             if (c0t + 16 <= a.Cout) {                                    // whole cout tile: 16-byte accesses
                 if (a.res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)rvo, c0t * 4, 0));
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), drs, (int)dvo, c0t * 4, 0);
+                buffer_store_b128(__builtin_bit_cast(u32x4, v), drs, (int)dvo, c0t * 4);
             } else {                                                     // ragged last tile (Cout % 16 != 0): dword accesses
                 const int c = c0t + (lane >> 4) * 4;
 #pragma unroll
@@ -446,7 +446,7 @@ __device__ __forceinline__ void conv_igemm_f32_body(const KA& a, float* lds, con
                 f32x4 v = tot2[pt] + bias2;
                 if (a.act2) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
                 if (c0t + 16 <= a.Cout2) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), drs2, (int)dvo[pt], c0t * 4, 0);
+                    buffer_store_b128(__builtin_bit_cast(u32x4, v), drs2, (int)dvo[pt], c0t * 4);
                 } else {                                                 // ragged last cout tile: dword stores
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -730,7 +730,7 @@ __device__ __forceinline__ void conv1x1_stream_f32_body(const KA& a, const Block
             }
             if (c0t + 16 <= a.Cout) {
                 if (a.res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)rvo, c0t * 4, 0));
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), drs, (int)dvo, c0t * 4, 0);
+                buffer_store_b128(__builtin_bit_cast(u32x4, v), drs, (int)dvo, c0t * 4);
             } else {                                                     // ragged last cout tile: dword accesses
                 const int c = c0t + g * 4;
 #pragma unroll

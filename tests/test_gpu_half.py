@@ -229,6 +229,28 @@ def test_config5_yolov8m_1280_half():
         assert err[2] <= 4.0 * noise[2] + 1e-4, (group, "max", err, noise)
 
 
+def test_head_final_conv_every_plan_repeated_has_no_dropped_store_data():
+    """Regression (round 3): a head's final conv -- pointwise, no activation, fp32 output -- computes the next tile's bias add two
+    instructions behind a 16-byte buffer store.  On gfx950 the store's data registers may not be rewritten by the next vector
+    instruction even when the store takes its offset from an SGPR (the form the compiler's hazard recogniser exempts), and 20 of the
+    95 launch plans of this shape stored zeros / the next tile's bits in dword 0 of pixel lanes 12-15, in a few per cent of the
+    launches.  common.h:buffer_store_b128 inserts the wait states; every plan, three times, against a float64 reference."""
+    from cvsd_amd import ops
+    n, h, w, cin, cout = 1, 160, 160, 192, 80
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wt = (rng.standard_normal((cout, cin, 1, 1), dtype=np.float32) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    want = np.einsum("nhwc,oc->nhwo", x.astype(np.float16).astype(np.float64), wt.astype(np.float16).astype(np.float64)[:, :, 0, 0]) + b
+    _, n_plans = ops.conv2d(x, wt, b, stride=1, silu=False, half=True, out_f32=True, return_n_plans=True)
+    tol = 1e-4 * max(1.0, float(np.abs(want).max()))
+    for rep in range(3):
+        for plan in range(n_plans):
+            y = ops.conv2d(x, wt, b, stride=1, silu=False, half=True, out_f32=True, plan=plan)
+            bad = np.argwhere(np.abs(y - want) > tol)
+            assert len(bad) == 0, (rep, plan, len(bad), bad[:4].tolist())
+
+
 def test_config5_at_its_stated_batch_of_two_equals_frame_by_frame():
     """BASELINE config 5 as stated: YOLOv8m, 1280x1280, half, TWO frames per GPU -- the batch-2 launch plans (other tiles, fused
     pairs, merged head convs) give the rows of the one-frame calls whose head tensor the test above bounds, bit for bit."""
