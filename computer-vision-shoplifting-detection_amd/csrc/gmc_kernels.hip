@@ -117,6 +117,73 @@ __device__ __forceinline__ void fill_region(const uint8_t* img, int h, int w, in
     __builtin_amdgcn_wave_barrier();
 }
 
+// The previous frame's window samples of one level (I, Scharr Ix, Iy at the win x win bilinear positions around (px, py)), this lane's
+// share.  patch<> evaluates every sample's four corners from global memory -- for the gradients six reflected byte loads per corner,
+// 364 loads per lane and level, four fifths of the kernel's time.  Here each INTEGER position of the (win + 1)^2 grid is evaluated
+// once: the image bytes the grid and its 3x3 stencils touch (a box of at most (win + 3)^2 pixels after reflection) are copied to LDS,
+// the three planes (byte, int16, int16 -- the stencil sums are integers, so nothing is rounded) are built from that copy, and the
+// bilinear samples read the planes.  Same integers, same float64 expression per sample: the same bits as patch<>.
+constexpr int kGridMax = 21 + 1;                                   // win + 1
+struct LkScratch {
+    uint8_t box[(21 + 3) * (21 + 3)];                              // image bytes under the grid and its stencils
+    uint8_t pI[kGridMax * kGridMax];
+    short pIx[kGridMax * kGridMax], pIy[kGridMax * kGridMax];
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void setup_patches(const uint8_t* img, int h, int w, double px, double py, int win, int lane, uint8_t* box, uint8_t* pI,
+                                              short* pIx, short* pIy, double (&I)[kMaxPer], double (&Ix)[kMaxPer], double (&Iy)[kMaxPer], int per) {
+    const int half = win / 2, G = win + 1;
+    const double x = px - half, y = py - half;
+    const double fx = floor(x), fy = floor(y);
+    const int ix = (int)fx, iy = (int)fy;
+    const double ax = x - fx, ay = y - fy;
+    const double w00 = (1 - ay) * (1 - ax), w01 = (1 - ay) * ax, w10 = ay * (1 - ax), w11 = ay * ax;
+    // image rows / columns the grid's reflected positions fall on (wave-uniform), one pixel more on each side for the stencils
+    int ylo = h, yhi = -1, xlo = w, xhi = -1;
+    for (int r = 0; r < G; ++r) {
+        const int yy = reflect101(iy + r, h), xx = reflect101(ix + r, w);
+        ylo = min(ylo, yy); yhi = max(yhi, yy); xlo = min(xlo, xx); xhi = max(xhi, xx);
+    }
+    ylo = max(0, ylo - 1); yhi = min(h - 1, yhi + 1); xlo = max(0, xlo - 1); xhi = min(w - 1, xhi + 1);
+    const int Hb = yhi - ylo + 1, Wb = xhi - xlo + 1;              // <= win + 3 each
+    wave_lds_fence();                                              // the previous level's readers of the box and the planes are done
+    for (int k = lane; k < Hb * Wb; k += 64) {
+        const int r = k / Wb, c = k - r * Wb;
+        box[k] = img[(size_t)(ylo + r) * w + (xlo + c)];
+    }
+    wave_lds_fence();
+    auto A = [&](int yy, int xx) { return (int)box[(yy - ylo) * Wb + (xx - xlo)]; };
+    for (int k = lane; k < G * G; k += 64) {
+        const int r = k / G, c = k - r * G;
+        const int yy = reflect101(iy + r, h), xx = reflect101(ix + c, w);
+        const int ym = reflect101(yy - 1, h), yp = reflect101(yy + 1, h), xm = reflect101(xx - 1, w), xp = reflect101(xx + 1, w);
+        pI[k] = (uint8_t)A(yy, xx);
+        pIx[k] = (short)(3 * (A(ym, xp) - A(ym, xm)) + 10 * (A(yy, xp) - A(yy, xm)) + 3 * (A(yp, xp) - A(yp, xm)));
+        pIy[k] = (short)(3 * (A(yp, xm) - A(ym, xm)) + 10 * (A(yp, xx) - A(ym, xx)) + 3 * (A(yp, xp) - A(ym, xp)));
+    }
+    wave_lds_fence();
+    const int W2 = win * win;
+#pragma unroll
+    for (int j = 0; j < kMaxPer; ++j) {
+        if (j >= per) break;
+        const int k = lane + 64 * j;
+        double vi = 0.0, vx = 0.0, vy = 0.0;
+        if (k < W2) {
+            const int r = k / win, c = k - r * win;
+            const int q = r * G + c;
+            vi = w00 * (double)pI[q] + w01 * (double)pI[q + 1] + w10 * (double)pI[q + G] + w11 * (double)pI[q + G + 1];
+            vx = w00 * (double)pIx[q] + w01 * (double)pIx[q + 1] + w10 * (double)pIx[q + G] + w11 * (double)pIx[q + G + 1];
+            vy = w00 * (double)pIy[q] + w01 * (double)pIy[q + 1] + w10 * (double)pIy[q + G] + w11 * (double)pIy[q + G + 1];
+        }
+        I[j] = vi; Ix[j] = vx; Iy[j] = vy;
+    }
+}
+
 // one wavefront per point; block = kLkWaves wavefronts (4: eight or sixteen points per block, meant to leave more CUs to the detector
 // pass this kernel runs beside, measured equal / 5-10 % slower on the track loop -- tools/lk_waves_ab.sh)
 #ifndef MI355_LK_WAVES
@@ -125,10 +192,12 @@ __device__ __forceinline__ void fill_region(const uint8_t* img, int h, int w, in
 constexpr int kLkWaves = MI355_LK_WAVES;
 __global__ __launch_bounds__(64 * kLkWaves) void lk_kernel(LkArgs a) {
     __shared__ uint8_t region[kLkWaves][(kRegMax * kRegMax + 15) & ~15];
+    __shared__ LkScratch scratch[kLkWaves];
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * kLkWaves + (threadIdx.x >> 6);
     if (i >= a.n) return;
     uint8_t* reg = region[threadIdx.x >> 6];
+    LkScratch& sc = scratch[threadIdx.x >> 6];
     const int win = a.win, half = win / 2, W2 = win * win;
     const int per = (W2 + 63) / 64;
     const int R = win + 1 + 2 * kMargin;
@@ -153,9 +222,13 @@ __global__ __launch_bounds__(64 * kLkWaves) void lk_kernel(LkArgs a) {
         if (!inside) { if (l == 0) ok = false; continue; }
         const double cx = fmin(fmax(px, (double)-half), (double)(w - 1 + half));
         const double cy = fmin(fmax(py, (double)-half), (double)(h - 1 + half));
+#if MI355_LK_GLOBAL_SETUP
         patch<0>(a.prev[l], h, w, cx, cy, win, lane, I, per);
         patch<1>(a.prev[l], h, w, cx, cy, win, lane, Ix, per);
         patch<2>(a.prev[l], h, w, cx, cy, win, lane, Iy, per);
+#else
+        setup_patches(a.prev[l], h, w, cx, cy, win, lane, sc.box, sc.pI, sc.pIx, sc.pIy, I, Ix, Iy, per);
+#endif
         double a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
         for (int j = 0; j < kMaxPer; ++j) {
