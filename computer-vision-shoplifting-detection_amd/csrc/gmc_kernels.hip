@@ -57,10 +57,27 @@ struct LkArgs {
     const float* pts; float* next; uint8_t* status;
 };
 
+// Sum over the 64 lanes, the same bits in every lane.  Four row_shr steps inside each row of 16 lanes (data-parallel-primitive moves:
+// a few cycles each, against ~100 for the LDS-crossbar permute a generic shuffle becomes), two row broadcasts, one read of lane 63.
+// The iteration of the Lucas-Kanade loop is latency-bound and does two of these back to back.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+    const double o = __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);    // 0.0 where the source lane is outside the row / masked
+    return v + o;
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v = dpp_add<0x111, 0xf>(v);          // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);          // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);          // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);          // row_shr:8  -> lane 15 of every row holds the row's sum
+    v = dpp_add<0x142, 0xa>(v);          // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);          // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
 
 // value of plane `kind` (0 = intensity, 1 = Scharr d/dx, 2 = Scharr d/dy of the same image) at integer position (y, x) of the
