@@ -92,6 +92,25 @@ def test_every_launch_plan_gives_the_same_bits(n, h, w, cin, cout, k, stride):
                                       err_msg=f"plan {plan} of {n_plans}")
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout", [(1, 80, 80, 64, 80), (1, 160, 160, 64, 64), (2, 40, 40, 128, 80)])
+def test_head_final_conv_without_activation_every_plan_repeated(n, h, w, cin, cout):
+    """Regression (round 3, common.h:buffer_store_b128): a head's final conv -- pointwise, NO activation -- computes the next tile's
+    bias add right behind a 16-byte buffer store; on gfx950 that rewrote the store's data registers too early in a few per cent of
+    the launches of some plans (zeros / the next tile's bits in dword 0 of pixel lanes 12-15; first seen as the streaming member of
+    a grouped launch).  Every plan, three times, bit for bit against the canonical-order oracle."""
+    from cvsd_amd import ops
+    from oracle import det
+    rng = np.random.default_rng(cin + cout + h)
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wt = (rng.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = det.conv2d(x, wt, b, stride=1, act=False, residual=None)
+    _, n_plans = ops.conv2d(x, wt, b, stride=1, silu=False, plan=0, return_n_plans=True)
+    for rep in range(3):
+        for plan in range(n_plans):
+            np.testing.assert_array_equal(ops.conv2d(x, wt, b, stride=1, silu=False, plan=plan), ref, err_msg=f"rep {rep} plan {plan} of {n_plans}")
+
+
 @pytest.mark.parametrize("n,h,w,cin,c1,stride,c2,silu2", [
     (2, 32, 32, 16, 32, 2, 32, True),        # model.1 -> model.2.cv1
     (1, 40, 40, 64, 64, 1, 64, False),       # cv2[i][1] -> cv2[i][2] (box logits, no activation)
