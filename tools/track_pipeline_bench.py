@@ -50,13 +50,7 @@ class Clip:
 
 
 big = YOLO(build_from_state_dict("yolov8n", sd), batch_chunk=64)
-for label, dev in (("GPU GMC", 0), ("host GMC", None)):
-    big.device = dev if dev is not None else big.device
-    if dev is None:
-        import cvsd_amd.sweep as S
-        orig = S.process_clip.__globals__["getattr"] if "getattr" in S.process_clip.__globals__ else None
-    process_clip(big, Clip(frames[:64]), batch=64)
-    t0 = time.perf_counter()
-    process_clip(big, Clip(frames), batch=64)
-    print(f"sweep batch 64, {label}: {n / (time.perf_counter() - t0):8.1f} frames/s")
-    break
+process_clip(big, Clip(frames[:64]), batch=64)              # plans of the 64-frame pass
+t0 = time.perf_counter()
+process_clip(big, Clip(frames), batch=64)
+print(f"sweep batch 64, GPU GMC: {n / (time.perf_counter() - t0):8.1f} frames/s")
