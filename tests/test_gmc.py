@@ -246,3 +246,21 @@ def test_host_cpp_corner_ordering_and_ransac_are_the_numpy_statements():
     assert gmc.estimate_affine_partial_2d_host(p[:1], q[:1])[0] is None
     # all points identical: no hypothesis survives
     assert gmc.estimate_affine_partial_2d_host(np.zeros((10, 2)), np.zeros((10, 2)))[0] is None
+
+
+def test_device_path_without_a_gpu_is_a_loud_error_not_a_fallback():
+    """GMC(device=k) never falls back to the host routines: without a usable GPU the step raises (and BYTETracker.update lets that
+    RuntimeError through -- only degenerate-geometry errors are bypassed, as Ultralytics' tracker does)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    frame = np.zeros((48, 64, 3), np.uint8)
+    with pytest.raises(RuntimeError):
+        gmc.GMC(device=0).apply(frame)
+    with pytest.raises(RuntimeError):
+        gmc.calc_optical_flow_pyr_lk(np.zeros((48, 64), np.uint8), np.zeros((48, 64), np.uint8), np.ones((3, 2), np.float32), device=0)
+    with pytest.raises(RuntimeError):
+        gmc.prepare_frame(frame, 2, device=0)
+    t = BYTETracker(gmc_device=0)
+    with pytest.raises(RuntimeError):
+        t.update(np.array([[10, 10, 30, 40, 0.9, 0]], np.float32), frame)
