@@ -41,22 +41,27 @@ def list_clips(list_path: str, videos_to_process: Optional[List[str]] = None) ->
 
 def process_clip(model, cap, batch: int = 64, conf: float = 0.1, classes=(0,), **predict_kw) -> np.ndarray:
     """All tracked boxes of one clip: array [rows, 6] = frame number (1-based), local track id, xywhn (centre x, centre y,
-    w, h).  Detection is batched; the tracker sees the frames one by one, in order (model.py:38 semantics)."""
+    w, h).  Detection is batched; the tracker sees the frames one by one, in order (model.py:38 semantics).
+
+    Three things run side by side: the detector pass of batch k + 1 (a worker thread inside the engine's C call), the tracker's
+    association of batch k on this thread, and -- on a GPU stream of its own -- the motion-compensation step of the NEXT frame,
+    enqueued as soon as the current frame's has been collected."""
+    from concurrent.futures import ThreadPoolExecutor
     from .results import Boxes, clip_boxes
     from .tracker import BYTETracker
     import torch
     tracker = BYTETracker(gmc_device=getattr(model, "device", None))     # motion compensation on the engine's GPU (csrc/gmc_kernels.hip)
     rows: List[List[float]] = []
-    buf, nums = [], []
 
-    def flush():
-        if not buf:
-            return
-        tracker.gmc.begin(buf[0])                              # the first frame's motion-compensation step runs beside the detector
+    def detect(buf):
         # a clip's last batch is filled up with copies of its last frame (their results are dropped): the engine plans -- and on
         # first sight times -- its launches per batch size, and a sweep would otherwise meet every size from 1 to batch - 1
         stack = np.stack(buf + [buf[-1]] * (batch - len(buf)))
-        results = model.predict(stack, conf=conf, classes=list(classes), **predict_kw)[:len(buf)]
+        return model.predict(stack, conf=conf, classes=list(classes), **predict_kw)[:len(buf)]
+
+    def track(fut, nums, buf):
+        tracker.gmc.begin(buf[0])                              # no-op when the previous batch's last frame already enqueued it
+        results = fut.result()
         for j, (n, frame, res) in enumerate(zip(nums, buf, results)):
             # every frame, empty ones too (frame_id / lost-track ageing); frame j + 1's step is enqueued while frame j is associated
             tracks = tracker.update(res.boxes.data.numpy(), frame, next_img=buf[j + 1] if j + 1 < len(buf) else None)
@@ -65,19 +70,31 @@ def process_clip(model, cap, batch: int = 64, conf: float = 0.1, classes=(0,), *
                 for box in b:
                     x = box.xywhn[0]
                     rows.append([float(int(n)), float(box.id), float(x[0]), float(x[1]), float(x[2]), float(x[3])])
-        buf.clear()
-        nums.clear()
 
-    while True:
-        success, frame = cap.read()
-        n = cap.get(CAP_PROP_POS_FRAMES)
-        if not success:
-            break
-        buf.append(frame)
-        nums.append(n)
-        if len(buf) >= batch:
-            flush()
-    flush()
+    def batches():
+        buf, nums = [], []
+        while True:
+            success, frame = cap.read()
+            n = cap.get(CAP_PROP_POS_FRAMES)
+            if not success:
+                break
+            buf.append(frame)
+            nums.append(n)
+            if len(buf) >= batch:
+                yield nums, buf
+                buf, nums = [], []
+        if buf:
+            yield nums, buf
+
+    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="detect") as pool:
+        pending = None
+        for nums, buf in batches():
+            fut = pool.submit(detect, buf)                     # batch k + 1 on the detector ...
+            if pending is not None:
+                track(*pending)                                # ... while batch k is tracked
+            pending = (fut, nums, buf)
+        if pending is not None:
+            track(*pending)
     cap.release()
     return np.asarray(rows, dtype=np.float64).reshape(-1, 6)
 
