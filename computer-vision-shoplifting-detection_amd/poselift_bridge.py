@@ -48,16 +48,20 @@ def video_to_poselift(model, frames: Iterable[np.ndarray], out_path: Optional[st
     from .tracker import BYTETracker
     if getattr(model, "task", "pose") != "pose":
         raise ValueError("video_to_poselift needs a pose model (e.g. yolov8n-pose)")
+    from concurrent.futures import ThreadPoolExecutor
     tracker = BYTETracker(gmc_device=gmc_device)
     w = PoseLiftWriter()
-    buf, n = [], first_frame
+    n = first_frame
 
-    def flush():
+    def detect(buf):
+        return model.predict(np.stack(buf), conf=min(conf, 0.1), **predict_kw)
+
+    def track(fut, buf):
         nonlocal n
-        if not buf:
-            return
-        for frame, res in zip(buf, model.predict(np.stack(buf), conf=min(conf, 0.1), **predict_kw)):
-            rows = tracker.update(res.boxes.data.numpy(), frame)      # every frame, empty ones too (frame_id / lost-track ageing)
+        tracker.gmc.begin(buf[0])                                     # device path only
+        for j, (frame, res) in enumerate(zip(buf, fut.result())):
+            # every frame, empty ones too (frame_id / lost-track ageing); the next frame's motion-compensation step is enqueued ahead
+            rows = tracker.update(res.boxes.data.numpy(), frame, next_img=buf[j + 1] if j + 1 < len(buf) else None)
             if len(rows):
                 rows = clip_boxes(rows.copy(), res.orig_shape)  # Results.update clips the track boxes to the frame
                 idx = rows[:, -1].astype(int)
@@ -67,13 +71,27 @@ def video_to_poselift(model, frames: Iterable[np.ndarray], out_path: Optional[st
             else:
                 w.add_frame(n, np.zeros((0, 8), np.float32), np.zeros((0, 17, 3), np.float32))
             n += 1
-        buf.clear()
 
-    for f in frames:
-        buf.append(f)
-        if len(buf) >= batch:
-            flush()
-    flush()
+    def batches():
+        buf = []
+        for f in frames:
+            buf.append(f)
+            if len(buf) >= batch:
+                yield buf
+                buf = []
+        if buf:
+            yield buf
+
+    # the detector pass of batch k + 1 runs on a worker thread (inside the engine's C call) while batch k is tracked here
+    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="detect") as pool:
+        pending = None
+        for buf in batches():
+            fut = pool.submit(detect, buf)
+            if pending is not None:
+                track(*pending)
+            pending = (fut, buf)
+        if pending is not None:
+            track(*pending)
     if out_path:
         w.save(out_path)
     return w.data
