@@ -617,6 +617,7 @@ __global__ __launch_bounds__(256, (PT == 8 ? (CT <= 3 ? 3 : 2) : 1)) void conv_i
     } else {
         // ---- first-stage image -> LDS behind the halo tile, fp16, pixel stride ldp2 = 32 * cib2 + 8 halfs ----
         _Float16* y1 = lds_h + 2 * a.lds_buf_floats;
+        if (a.lds_buf_floats == 0) __syncthreads();              // the image takes the halo tile's place: every wave is done reading the tile
         const int P = WP * PT * 16, g = lane >> 4;
         const int c1pad = a.cib2 * 32, c1t = a.n_ctiles * 16;
         // channels [16 * n_ctiles, 32 * cib2) of every pixel are zero: their weights are, and 0 * garbage must not be NaN

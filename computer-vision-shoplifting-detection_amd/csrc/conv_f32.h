@@ -338,6 +338,7 @@ __device__ __forceinline__ void conv_igemm_f32_body(const KA& a, float* lds, con
             // The first conv may carry the Bottleneck's residual (C2f / C3 with shortcut): y = silu(tot + bias) + residual, read
             // through a descriptor over this image of the residual slice (pixels outside the tile / image read zeros).
             float* y1 = lds + a.lds_buf_floats;
+            if (a.lds_buf_floats == 0) __syncthreads();          // the image takes the halo tile's place: every wave is done reading the tile
             const __amdgpu_buffer_rsrc_t rrs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res + (size_t)b * (size_t)a.img_res : a.dst), 0,
                                                                                   a.res ? (int)((unsigned)a.img_res * 4u) : 0, 0x00020000);
 #pragma unroll

@@ -130,6 +130,17 @@ std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int ci
                     if (cost < best.cost) { best = Plan{CT, WP, TW, TH, ck, lds, cost, 1, f2_cin16 ? stage_floats : 0, PTsel}; best.G = G; best.f2 = f2_cin16 != 0; }
                 }
                 if (best.cost < 1e30) out.push_back(best);
+                // fused pointwise stage, one cout group: the first conv's output image may take the halo tile's place in LDS (the tile is
+                // dead once the K loop is over; one more barrier) -- LDS per block = max instead of sum, i.e. more blocks per CU
+                static const int alias_on = env_int("MI355_F2_ALIAS", 1);
+                if (alias_on && best.cost < 1e30 && best.f2 && G == 1) {
+                    Plan al = best;
+                    const size_t stage_b = (size_t)al.buf_floats * 4, img_b = al.lds - stage_b;
+                    if (img_b > 0 && std::max(stage_b, img_b) + 4096 <= al.lds) {          // worth a plan only if it frees a few KiB
+                        al.lds = std::max(stage_b, img_b); al.buf_floats = 0; al.cost = best.cost * 0.999;
+                        out.push_back(al);
+                    }
+                }
             }
             }
         }
