@@ -19,7 +19,15 @@ class Mi355Error(RuntimeError):
 
 
 class Opts(C.Structure):
-    _fields_ = [("struct_size", C.c_int), ("batch_chunk", C.c_int), ("half", C.c_int), ("reserved", C.c_int * 5)]
+    _fields_ = [("struct_size", C.c_int), ("batch_chunk", C.c_int), ("half", C.c_int), ("fast_act", C.c_int), ("autotune", C.c_int),
+                ("streams", C.c_int), ("flags", C.c_int), ("reserved", C.c_int), ("plan_dir", C.c_char_p), ("plan_cache_dir", C.c_char_p)]
+
+
+# mi355_opts.flags (include/mi355_yolo.h)
+OPT_NO_FUSE_UPSAMPLE, OPT_NO_FUSE_1X1, OPT_NO_FUSE_TAIL, OPT_NO_GROUPS = 0x01, 0x02, 0x04, 0x08
+OPT_NO_MEM_REUSE, OPT_HIP_GRAPH, OPT_NO_DIRECT_ROWS, OPT_NO_PASS_TUNE = 0x10, 0x20, 0x40, 0x80
+# launch-plan files shipped with the package: the tuned choices of the benchmarked workloads on MI355X (plans/README.md)
+PLAN_DIR = os.path.join(HERE, "plans")
 
 
 class Det(C.Structure):

@@ -18,7 +18,7 @@ struct ConvArgs {
     const float* bias;                 // padded to a multiple of 16 floats
     int B, Hin, Win, Hout, Wout;
     int Cin, Cout;
-    int k, stride, pad, act;           // k in {1,3}; act: 0 none, 1 SiLU
+    int k, stride, pad, act;           // k in {1,3}; act: 0 none, 1 SiLU (canonical, bit-reproducible), 2 SiLU on v_exp / v_rcp (fp32 kernels, opts.fast_act)
     const float* zeros;                // device pointer to >= 16 zero bytes (required)
     // half=True path (conv_igemm_f16.hip): dtype 1 = src / res / wpk hold fp16 (pack_conv_weights_f16), strides count halfs;
     // dst holds fp16 too unless out_f32 (the head's final convs).  The pointers keep their float* type; only bytes matter.
@@ -122,6 +122,7 @@ struct StemArgs {
     const float* lut;                  // device [256]: (float)i / 255.0f
     int B, H, W, Hout, Wout, Cout, k, stride, pad;
     int out_half = 0;                  // 1: dst holds fp16 (dst_cs counts halfs); arithmetic stays fp32, one rounding on the store
+    int fast_act = 0;                  // fp32 output: 1 = SiLU on v_exp / v_rcp (opts.fast_act) instead of the canonical form
 };
 const char* launch_stem(const StemArgs& a, hipStream_t st);
 const char* launch_upsample2x(const float* src, int src_cs, float* dst, int dst_cs, int B, int H, int W, int C,
@@ -193,8 +194,11 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 #endif
 typedef unsigned mi355_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void buffer_store_b128(mi355_u32x4 v, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, soffset, 0);
 #if MI355_STORE_WAIT                       // -DMI355_STORE_WAIT=0 (tools/ab_build.sh): the regression tests then fail, which is how they are checked
+    __builtin_amdgcn_sched_barrier(0);     // nothing that precedes the store in program order may be moved into the store .. s_nop window
+#endif
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, soffset, 0);
+#if MI355_STORE_WAIT
     asm volatile("s_nop 1" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #endif

@@ -34,6 +34,18 @@ namespace mi355 {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_f(float v) { return det_silu(v); }
+// act == 2 (mi355_opts.fast_act, tolerance mode): x * rcp(1 + 2^(-x log2 e)) on the hardware transcendental units (v_exp_f32 / v_rcp_f32, 8 issue
+// cycles each) -- 5 vector instructions per output instead of the canonical form's 24, ~1e-7 relative error, NOT reproducible on a CPU.
+// The branch is block-uniform (act is a kernel argument).
+__device__ __forceinline__ float silu_fast_f(float v) {
+    const float e = __builtin_amdgcn_exp2f(v * -1.44269504088896341f);
+    return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
+    if (act == 2) { v[0] = silu_fast_f(v[0]); v[1] = silu_fast_f(v[1]); v[2] = silu_fast_f(v[2]); v[3] = silu_fast_f(v[3]); }
+    else v = act4(v, act);
+    return v;
+}
 
 // bias + SiLU (+ residual) and the 16-byte stores: a lane holds 4 consecutive couts of one pixel per tile.
 // Two passes: all the ALU work first (16 independent SiLU chains per lane interleave freely), then the stores back to
@@ -43,7 +55,16 @@ __device__ __forceinline__ float silu_f(float v) { return det_silu(v); }
 template <int STRIDE, int PT, int CT, int WP, class KA>
 __device__ __forceinline__ void conv_epilogue(const KA& a, f32x4 (&acc)[CT][PT], const f32x4 (&bias4)[CT], int lane, int wp,
                                               int ct0, int b, int oy0, int ox0, int npix) {
-    if (a.act) {
+    if (a.act == 2) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                f32x4 v = acc[ct][pt] + bias4[ct];
+                v[0] = silu_fast_f(v[0]); v[1] = silu_fast_f(v[1]); v[2] = silu_fast_f(v[2]); v[3] = silu_fast_f(v[3]);
+                acc[ct][pt] = v;
+            }
+    } else if (a.act) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -107,7 +128,7 @@ __device__ __forceinline__ void store_tile(f32x4 v, const float* bias, int act, 
     const int c = ctile * 16 + (lane >> 4) * 4;
     if (!ok || c >= cout) return;
     v += *(const f32x4*)(bias + c);
-    if (act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+    v = act4(v, act);
     float* d = dst + po * dst_cs + c;
     if (c + 3 < cout) {
         if (res) v += *(const f32x4*)(res + po * res_cs + c);
@@ -356,7 +377,7 @@ __device__ __forceinline__ void conv_igemm_f32_body(const KA& a, float* lds, con
                 for (int ct = 0; ct < CT; ++ct) {
                     if (ct0 + ct >= a.n_ctiles) continue;
                     f32x4 v = tot[ct][pt] + bias4[ct];
-                    if (a.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                    v = act4(v, a.act);
                     if (a.res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs1, (int)rvo, (ct0 + ct) * 64, 0));
                     *(f32x4*)(y1 + ((wp * PT + pt) * 16 + (lane & 15)) * a.ldp2 + (ct0 + ct) * 16 + (lane >> 4) * 4) = v;
                 }
@@ -445,7 +466,7 @@ __device__ __forceinline__ void conv_igemm_f32_body(const KA& a, float* lds, con
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
                 f32x4 v = tot2[pt] + bias2;
-                if (a.act2) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                v = act4(v, a.act2);
                 if (c0t + 16 <= a.Cout2) {
                     buffer_store_b128(__builtin_bit_cast(u32x4, v), drs2, (int)dvo[pt], c0t * 4);
                 } else {                                                 // ragged last cout tile: dword stores
@@ -604,7 +625,7 @@ __device__ __forceinline__ void conv_splitk_f32_body(const KA& a, float* lds, co
         const int oy = oy0 + ly, ox = ox0 + lx;
         if (!((p < npix) && (oy < a.Hout) && (ox < a.Wout)) || ctile >= a.n_ctiles || c >= a.Cout) continue;
         f32x4 v = tot + *(const f32x4*)(a.bias + ctile * 16 + (lane >> 4) * 4);
-        if (a.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+        v = act4(v, a.act);
         const size_t po = ((size_t)b * a.Hout + oy) * a.Wout + ox;
         float* d = a.dst + po * a.dst_cs + c;
         if (c + 3 < a.Cout) {
@@ -726,9 +747,7 @@ __device__ __forceinline__ void conv1x1_stream_f32_body(const KA& a, const Block
             const int c0t = (ct0 + ct) * 16;                             // wave-uniform
             if (c0t >= a.Cout) continue;
             f32x4 v = acc[ct][pt] + bias4[ct];
-            if (a.act) {
-                v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
-            }
+            v = act4(v, a.act);
             if (c0t + 16 <= a.Cout) {
                 if (a.res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)rvo, c0t * 4, 0));
                 buffer_store_b128(__builtin_bit_cast(u32x4, v), drs, (int)dvo, c0t * 4);
@@ -901,7 +920,7 @@ __global__ __launch_bounds__(256, (CT <= 2 ? (NKK <= 4 ? MI355_PIPE_MINWAVES : 2
                     f32x4 v = acc[ct][pt] + bias4[ct];
                     acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     if (!ok || c >= a.Cout) continue;
-                    if (a.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                    v = act4(v, a.act);
                     float* d = a.dst + (size_t)p * a.dst_cs + c;
                     if (c + 3 < a.Cout) {
                         if (a.res) v += *(const f32x4*)(a.res + (size_t)p * a.res_cs + c);

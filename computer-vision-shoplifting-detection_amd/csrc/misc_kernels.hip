@@ -167,11 +167,16 @@ __global__ __launch_bounds__(256) void stem_mfma_u8(StemArgs a) {
                 float* d = a.dst + po * a.dst_cs + c;
                 if (c + 3 < a.Cout) {
                     f32x4 o;
+                    if (a.fast_act) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = silu_m(v[j] + a.bias[c + j]);
+                        for (int j = 0; j < 4; ++j) o[j] = silu_fast(v[j] + a.bias[c + j]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = silu_m(v[j] + a.bias[c + j]);
+                    }
                     *(f32x4*)d = o;
                 } else {
-                    for (int j = 0; j < 4 && c + j < a.Cout; ++j) d[j] = silu_m(v[j] + a.bias[c + j]);
+                    for (int j = 0; j < 4 && c + j < a.Cout; ++j) d[j] = a.fast_act ? silu_fast(v[j] + a.bias[c + j]) : silu_m(v[j] + a.bias[c + j]);
                 }
             }
         }

@@ -47,7 +47,12 @@ class YOLO:
     """
 
     def __init__(self, model: Union[str, bytes, os.PathLike], task: Optional[str] = None, device: int = 0,
-                 batch_chunk: int = 0, verbose: bool = False, half: bool = False):
+                 batch_chunk: int = 0, verbose: bool = False, half: bool = False, fast_act: bool = False, autotune: int = 0,
+                 streams: int = 0, flags: int = 0, plan_dir: Optional[str] = None, plan_cache_dir: Optional[str] = None):
+        """Engine options are ``mi355_opts`` (include/mi355_yolo.h): ``fast_act`` = the v_exp / v_rcp SiLU on the fp32 path (tolerance
+        mode; the default is the canonical, bit-reproducible arithmetic), ``autotune`` / ``streams`` / ``flags`` (``_lib.OPT_*``) as the
+        header documents them, ``plan_dir`` = directory of shipped launch-plan files (default: the package's ``plans/``; "" = none),
+        ``plan_cache_dir`` = where freshly timed choices are kept (default ~/.cache/mi355yolo; "" = not persisted)."""
         lib = _lib.lib()
         self._lock = threading.Lock()          # Ultralytics serialises predict() with a per-predictor lock
         self._h = C.c_void_p()
@@ -55,7 +60,12 @@ class YOLO:
         self.half = bool(half)                 # precision of the primary engine (predict(half=None) uses it)
         self.device = int(device)
         self._batch_chunk = int(batch_chunk)
-        opts = _lib.Opts(struct_size=C.sizeof(_lib.Opts), batch_chunk=int(batch_chunk), half=int(self.half))
+        self.fast_act = bool(fast_act)
+        pd = _lib.PLAN_DIR if plan_dir is None else plan_dir
+        self._opt_kw = dict(batch_chunk=int(batch_chunk), fast_act=int(self.fast_act), autotune=int(autotune), streams=int(streams), flags=int(flags),
+                            plan_dir=os.fsencode(pd) if pd else None,
+                            plan_cache_dir=None if plan_cache_dir is None else os.fsencode(plan_cache_dir))
+        opts = _lib.Opts(struct_size=C.sizeof(_lib.Opts), half=int(self.half), **self._opt_kw)
         if isinstance(model, (bytes, bytearray, memoryview)):
             blob = bytes(model)
             self.ckpt_path = None
@@ -106,7 +116,7 @@ class YOLO:
         if half is None or bool(half) == self.half:
             return self._h
         if not self._h_other.value:
-            opts = _lib.Opts(struct_size=C.sizeof(_lib.Opts), batch_chunk=self._batch_chunk, half=int(bool(half)))
+            opts = _lib.Opts(struct_size=C.sizeof(_lib.Opts), half=int(bool(half)), **self._opt_kw)
             _lib.check(_lib.lib().mi355_yolo_create_from_memory(self._blob, len(self._blob), self.device, C.byref(opts),
                                                                 C.byref(self._h_other)))
         return self._h_other
@@ -304,7 +314,7 @@ class YOLO:
         hsh, src, nl, ab, au = C.c_ulonglong(), C.c_int(), C.c_int(), C.c_longlong(), C.c_longlong()
         _lib.check(_lib.lib().mi355_yolo_plan_info(getattr(self, "_last_handle", self._h), C.byref(hsh), C.byref(src), C.byref(nl), C.byref(ab),
                                                    C.byref(au)))
-        return {"plan_hash": f"{hsh.value:016x}", "plan_source": ("static", "memory", "file", "tuned")[src.value & 3],
+        return {"plan_hash": f"{hsh.value:016x}", "plan_source": ("static", "memory", "cache", "tuned", "file")[src.value] if 0 <= src.value <= 4 else str(src.value),
                 "launches_per_pass": nl.value, "activation_bytes": ab.value, "activation_bytes_unshared": au.value}
 
     def set_profiling(self, on: bool = True) -> None:

@@ -43,14 +43,36 @@ extern "C" {
 
 typedef struct mi355_yolo mi355_yolo;   /* opaque engine handle */
 
-/* Engine options; zero-initialise and set struct_size = sizeof(mi355_opts). 0 means "default". */
+/* Engine options; zero-initialise and set struct_size = sizeof(mi355_opts). 0 / NULL means "default".  A caller built against an
+ * earlier header (smaller struct_size) keeps working: fields beyond its struct_size take their defaults.
+ * Every behaviour-changing knob of the engine is here; the MI355_* environment variables listed in INTEGRATION.md section 5 are
+ * A/B overrides for kernel experiments (tools/), not configuration. */
+#define MI355_OPT_NO_FUSE_UPSAMPLE  0x01   /* always launch the nearest-2x upsample kernel (never read through the consuming 1x1 conv) */
+#define MI355_OPT_NO_FUSE_1X1       0x02   /* never run a Conv3x3 -> Conv1x1 pair as one launch */
+#define MI355_OPT_NO_FUSE_TAIL      0x04   /* never run a C2f tail (last Bottleneck conv + C2f.cv2) as one launch */
+#define MI355_OPT_NO_GROUPS         0x08   /* no grouped launches / step schedule in the latency-bound regime (<= 5 frames per pass) */
+#define MI355_OPT_NO_MEM_REUSE      0x10   /* one region per graph tensor instead of the liveness-shared arena */
+#define MI355_OPT_HIP_GRAPH         0x20   /* replay stem..decode of a chunk as a hipGraph (measured slower on ROCm 7.2; off) */
+#define MI355_OPT_NO_DIRECT_ROWS    0x40   /* small calls: copy rows to the host instead of writing them from the NMS kernel */
+#define MI355_OPT_NO_PASS_TUNE      0x80   /* autotuner: skip the whole-pass re-check of fusion / group decisions */
 typedef struct mi355_opts {
     int struct_size;
     int batch_chunk;      /* frames pushed through the net per pass (default 64); larger batches are looped */
     int half;             /* 1 = Ultralytics' half=True (engine/predictor.py: model.half(), im.half()): activations (the /255
                            * input included) and weights stored as fp16, fp32 accumulate / bias / SiLU, head logits, decode and NMS in fp32.
                            * Results then differ from the fp32 path by fp16 rounding (not a bit-exact mode). */
-    int reserved[5];
+    int fast_act;         /* fp32 path only. 0 (default): the canonical SiLU x / (1 + exp(-x)) with a reproducible exp and IEEE division --
+                           * results are bit-identical to oracle/det_oracle.c.  1: v_exp_f32 / v_rcp_f32 SiLU in the conv epilogues (as the
+                           * half path has it): ~1e-6 relative per activation, NOT bit-exact, tolerance-tested against float64. */
+    int autotune;         /* candidate launch plans timed per conv when a shape is first seen: 0 = default (32; 28 for half), -1 = off
+                           * (the planner's static guess), n > 0 = n */
+    int streams;          /* HIP streams the ops of a pass of >= 6 frames are dealt to along the dependency DAG: 0 = default (4), 1 = one */
+    int flags;            /* MI355_OPT_* */
+    int reserved;
+    const char* plan_dir;        /* read-only directory of SHIPPED launch-plan files (cvsd_amd/plans): looked up first, so that every process
+                                  * on the same GPU model runs the same launch sequence without timing anything.  NULL = none */
+    const char* plan_cache_dir;  /* writable directory where freshly timed choices are kept (and found again): NULL = ~/.cache/mi355yolo,
+                                  * "" = do not persist */
 } mi355_opts;
 
 /* One post-NMS detection, coordinates in ORIGINAL-image pixels (after scale_boxes / scale_coords).
@@ -142,7 +164,7 @@ int  mi355_yolo_raw_head(mi355_yolo* h, const uint8_t* bgr_nhwc, int n, int heig
 
 /* Launch plans of the shape last run: plan_hash identifies the candidate lists AND the choice per conv (two runs with the same
  * hash launch the same kernels with the same grids); source 0 = static guess (autotune off), 1 = this process's memory,
- * 2 = plan file, 3 = timed now; launches = kernel launches of one pass (stem .. last conv; decode and NMS follow);
+ * 2 = this machine's plan cache, 3 = timed now, 4 = shipped plan file (opts.plan_dir); launches = kernel launches of one pass (stem .. last conv; decode and NMS follow);
  * activation_bytes = device memory held by the activation arena (buffers whose lifetimes cannot overlap under any legal
  * schedule share bytes), activation_bytes_unshared = what one region per graph tensor would take.  Any out pointer may be NULL. */
 int  mi355_yolo_plan_info(const mi355_yolo* h, unsigned long long* plan_hash, int* source, int* launches,
