@@ -43,7 +43,7 @@ __device__ __forceinline__ float silu_fast_f(float v) {
 }
 __device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
     if (act == 2) { v[0] = silu_fast_f(v[0]); v[1] = silu_fast_f(v[1]); v[2] = silu_fast_f(v[2]); v[3] = silu_fast_f(v[3]); }
-    else v = act4(v, act);
+    else if (act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
     return v;
 }
 
