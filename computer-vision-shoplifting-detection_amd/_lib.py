@@ -104,6 +104,23 @@ SIGNATURES = {
     "mi355_gmc_step_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]),
     "mi355_gmc_step_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_tracker_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "mi355_tracker_destroy": (None, [C.c_void_p]),
+    "mi355_tracker_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "mi355_tracker_last_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "mi355_tracker_state": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p]),
+    "mi355_tracker_tracks": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "mi355_kalman_initiate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_kalman_predict": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi355_kalman_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_kalman_warp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_lapjv": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]),
+    "mi355_gmc_prepare_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
+    "mi355_gmc_track_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "mi355_gmc_track_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi355_gmc_track_reset": (C.c_int, [C.c_void_p]),
+    "mi355_gmc_track_state": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, C.c_void_p, C.c_void_p, C.c_int]),
     "mi355_op_stem": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_int, C.c_int, C.c_void_p]),
     "mi355_letterbox_shape": (C.c_int, [C.c_int, C.c_int, C.c_int, _i32p, _i32p]),

@@ -13,6 +13,8 @@
 #include <thread>
 #include <vector>
 
+#pragma clang fp contract(off)      // float64 expressions are compared bit for bit with their numpy statements
+
 namespace {
 
 inline int reflect101(int i, int n) {          // BORDER_REFLECT_101
@@ -159,6 +161,76 @@ extern "C" int mi355_gmc_pyr_lk(const uint8_t* prev, const uint8_t* cur, int hei
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; ++t) th.emplace_back(work, (int)((long long)n * t / nthreads), (int)((long long)n * (t + 1) / nthreads));
     for (auto& t : th) t.join();
+    return 0;
+}
+
+// ---- frame preparation on the host (the device form is csrc/gmc_kernels.hip: gray_resize_kernel, min_eig_kernel, corner_mask_kernel) ----
+// cv2.cvtColor(BGR2GRAY) + cv2.resize(INTER_LINEAR) in their fixed-point arithmetic, cornerMinEigenVal (3x3 Sobel scaled by
+// 1 / (4 * block * 255), 3x3 box sums of the products in row-major order, smaller eigenvalue, float64 -> float32) and the mask of the
+// corners goodFeaturesToTrack keeps before it orders them (THRESH_TOZERO at quality * max, 3x3 non-maximum suppression, border
+// excluded).  Same expressions in the same order as the kernels, so the plane and the corner list are the same on both paths.
+// xtab / ytab: per output column / row (source index, tap 0, tap 1), 11-bit taps; unused when oh x ow is the frame size.
+extern "C" int mi355_gmc_prepare_host(const uint8_t* bgr, int height, int width, int oh, int ow, const int* xtab, const int* ytab, double quality,
+                                      uint8_t* gray_out, float* eig_out, uint8_t* ok_out) {
+    if (!bgr || height <= 0 || width <= 0 || oh <= 0 || ow <= 0 || !gray_out || !eig_out || !ok_out) return -1;
+    const bool resize = !(oh == height && ow == width);
+    if (resize && (!xtab || !ytab)) return -1;
+    auto luma = [&](int yy, int xx) {
+        const uint8_t* p = bgr + ((size_t)yy * width + xx) * 3;
+        return (int)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14);
+    };
+    for (int y = 0; y < oh; ++y)
+        for (int x = 0; x < ow; ++x) {
+            if (!resize) { gray_out[(size_t)y * ow + x] = (uint8_t)luma(y, x); continue; }
+            const int xi = xtab[3 * x], xa0 = xtab[3 * x + 1], xa1 = xtab[3 * x + 2];
+            const int yi = ytab[3 * y], yb0 = ytab[3 * y + 1], yb1 = ytab[3 * y + 2];
+            const int xj = std::min(xi + 1, width - 1), yj = std::min(yi + 1, height - 1);
+            const int h0 = luma(yi, xi) * xa0 + luma(yi, xj) * xa1;
+            const int h1 = luma(yj, xi) * xa0 + luma(yj, xj) * xa1;
+            int v = (((yb0 * (h0 >> 4)) >> 16) + ((yb1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            gray_out[(size_t)y * ow + x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    const int h = oh, w = ow;
+    const uint8_t* g = gray_out;
+    // Sobel products once per pixel, then the 3x3 sums over the reflect-padded product planes
+    std::vector<double> pxx((size_t)h * w), pxy((size_t)h * w), pyy((size_t)h * w);
+    const double sc = 1.0 / (4.0 * 3.0 * 255.0);
+    auto G = [&](int yy, int xx) { return (double)g[(size_t)reflect101(yy, h) * w + reflect101(xx, w)]; };
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const double dx = ((G(y - 1, x + 1) - G(y - 1, x - 1)) + 2 * (G(y, x + 1) - G(y, x - 1)) + (G(y + 1, x + 1) - G(y + 1, x - 1))) * sc;
+            const double dy = ((G(y + 1, x - 1) - G(y - 1, x - 1)) + 2 * (G(y + 1, x) - G(y - 1, x)) + (G(y + 1, x + 1) - G(y - 1, x + 1))) * sc;
+            const size_t k = (size_t)y * w + x;
+            pxx[k] = dx * dx; pxy[k] = dx * dy; pyy[k] = dy * dy;
+        }
+    float mx = 0.f;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            double sxx = 0.0, sxy = 0.0, syy = 0.0;
+            for (int i = -1; i <= 1; ++i)
+                for (int j = -1; j <= 1; ++j) {
+                    const size_t k = (size_t)reflect101(y + i, h) * w + reflect101(x + j, w);
+                    sxx += pxx[k]; sxy += pxy[k]; syy += pyy[k];
+                }
+            const double a = sxx * 0.5, b = sxy, c = syy * 0.5;
+            const float e = (float)((a + c) - std::sqrt((a - c) * (a - c) + b * b));
+            eig_out[(size_t)y * w + x] = e;
+            if (e > mx) mx = e;
+        }
+    const float thr = (float)((double)mx * quality);
+    auto T = [&](int yy, int xx) {
+        if (yy < 0 || yy >= h || xx < 0 || xx >= w) return -std::numeric_limits<float>::infinity();
+        const float v = eig_out[(size_t)yy * w + xx];
+        return v > thr ? v : 0.f;
+    };
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const float v = T(y, x);
+            float d = -std::numeric_limits<float>::infinity();
+            for (int i = -1; i <= 1; ++i)
+                for (int j = -1; j <= 1; ++j) d = std::max(d, T(y + i, x + j));
+            ok_out[(size_t)y * w + x] = (mx > 0.f && v != 0.f && v == d && y > 0 && y < h - 1 && x > 0 && x < w - 1) ? 1 : 0;
+        }
     return 0;
 }
 

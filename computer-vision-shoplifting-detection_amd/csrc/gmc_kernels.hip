@@ -543,11 +543,27 @@ struct mi355_gmc {
     // the pending step
     bool pending = false; int oh = 0, ow = 0, n_lk = 0;
     size_t o_hgray = 0, o_heig = 0, o_hok = 0, o_hnext = 0, o_hstatus = 0;
+    // ---- GMC.apply_sparseoptflow's state machine (mi355_gmc_track_*): the previous frame's plane and ordered corners live here, so a
+    // step is two calls from the tracker's language binding (enqueue, collect -> 2 x 3 matrix) and nothing per frame is done in it
+    bool host = false;                                         // mi355_gmc_create(-1): every stage in host C++ (csrc/gmc_host.cpp)
+    int downscale = 2;
+    std::vector<int> xt, yt; int tkey[4] = {0, 0, 0, 0};       // INTER_LINEAR tables of (height, width, oh, ow)
+    std::vector<uint8_t> prev_gray, cur_gray, ok; std::vector<float> eig;
+    std::vector<float> prev_pts, lk_pts, next_pts; std::vector<uint8_t> status;
+    int prev_h = 0, prev_w = 0; bool have_prev_pts = false;
+    bool track_pending = false; int t_oh = 0, t_ow = 0, t_n = 0;
+    std::vector<uint8_t> host_frame; int hf_h = 0, hf_w = 0;   // host object: the frame of the pending step
 };
 
 extern "C" int mi355_gmc_create(int device, mi355_gmc** out) {
-    if (!out || device < 0) return -1;
+    if (!out || device < -1) return -1;
     *out = nullptr;
+    if (device == -1) {                                         // host object: no HIP call is ever made through it
+        mi355_gmc* g = new mi355_gmc();
+        g->device = -1; g->host = true;
+        *out = g;
+        return 0;
+    }
     GCHK(hipSetDevice(device));
     mi355_gmc* g = new mi355_gmc();
     g->device = device;
@@ -558,6 +574,7 @@ extern "C" int mi355_gmc_create(int device, mi355_gmc** out) {
 
 extern "C" void mi355_gmc_destroy(mi355_gmc* g) {
     if (!g) return;
+    if (g->host) { delete g; return; }
     (void)hipSetDevice(g->device);
     if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
     if (g->d_front) (void)hipFree(g->d_front);
@@ -573,6 +590,7 @@ extern "C" void mi355_gmc_destroy(mi355_gmc* g) {
 extern "C" int mi355_gmc_step_begin(mi355_gmc* g, const uint8_t* bgr, int height, int width, int oh, int ow, const int* xtab, const int* ytab,
                                     double quality, const float* prev_pts, int n_prev, int win, int max_level, int max_iters, double eps,
                                     double min_eig) {
+    if (g && g->host) return -1;
     if (!g || !bgr || height <= 0 || width <= 0 || oh <= 0 || ow <= 0 || n_prev < 0 || (n_prev > 0 && !prev_pts) || win < 3 || !(win & 1) || win > 21 ||
         max_level < 0)
         return -1;
@@ -671,12 +689,134 @@ extern "C" int mi355_gmc_step_begin(mi355_gmc* g, const uint8_t* bgr, int height
 // Collect the enqueued step: gray / eig / ok of oh * ow elements, next_pts [n_prev][2] and status [n_prev] (untouched when the step
 // had n_prev == 0).
 extern "C" int mi355_gmc_step_finish(mi355_gmc* g, uint8_t* gray_out, float* eig_out, uint8_t* ok_out, float* next_pts, uint8_t* status) {
-    if (!g || !g->pending || !gray_out || !eig_out || !ok_out || (g->n_lk > 0 && (!next_pts || !status))) return -1;
+    if (!g || g->host || !g->pending || !gray_out || !eig_out || !ok_out || (g->n_lk > 0 && (!next_pts || !status))) return -1;
     GCHK(hipSetDevice(g->device));
     g->pending = false;
     if (hipStreamSynchronize(g->stream) != hipSuccess) { (void)hipGetLastError(); g->have_prev = false; return -2; }
     const size_t np = (size_t)g->oh * g->ow;
     std::memcpy(gray_out, g->h_pin + g->o_hgray, np); std::memcpy(eig_out, g->h_pin + g->o_heig, np * 4); std::memcpy(ok_out, g->h_pin + g->o_hok, np);
     if (g->n_lk > 0) { std::memcpy(next_pts, g->h_pin + g->o_hnext, (size_t)g->n_lk * 8); std::memcpy(status, g->h_pin + g->o_hstatus, (size_t)g->n_lk); }
+    return 0;
+}
+
+// ---- the whole step of GMC.apply_sparseoptflow on the object (ultralytics/trackers/utils/gmc.py, reached from /root/reference/model.py:38) ----
+// track_begin = enqueue: frame preparation of `bgr` and Lucas-Kanade tracking of the previous frame's corners into it (GPU object: on the
+// object's stream, returns at once; host object: the frame is copied and the work happens in track_finish).  track_finish = collect:
+// orders the new frame's corners (kept for the next step), estimates the partial affine transform prev -> cur from the tracked pairs
+// (RANSAC, seed 0) when more than 4 survive, scales its translation back to frame pixels.  H_out: 6 doubles, row-major 2 x 3; the
+// identity on the first frame of a plane size, when the previous frame had no corners, or when too few points were tracked.
+namespace {
+constexpr int kMaxCorners = 1000, kLkWin = 21, kLkLevels = 3, kLkIters = 30;
+constexpr double kQuality = 0.01, kLkEps = 0.01, kLkMinEig = 1e-4, kRansacThr = 3.0, kRansacConf = 0.99;
+constexpr int kRansacIters = 2000;
+
+// INTER_LINEAR sample table of a dn-long axis resampled from sn: (source index, tap 0, tap 1), 11-bit taps, float32 coordinates as cv2
+void linear_table(int dn, int sn, std::vector<int>& tab) {
+    tab.resize((size_t)dn * 3);
+    const double scale = (double)sn / dn;
+    for (int d = 0; d < dn; ++d) {
+        float fx = (float)((d + 0.5) * scale - 0.5);
+        int s0 = (int)floorf(fx);
+        fx -= (float)s0;
+        if (s0 < 0) { s0 = 0; fx = 0.f; }
+        if (s0 >= sn - 1) { s0 = sn - 1; fx = 0.f; }
+        tab[d * 3] = s0;
+        tab[d * 3 + 1] = (int)lrintf((1.f - fx) * 2048.f);
+        tab[d * 3 + 2] = (int)lrintf(fx * 2048.f);
+    }
+}
+}  // namespace
+
+extern "C" int mi355_gmc_track_begin(mi355_gmc* g, const uint8_t* bgr, int height, int width, int downscale) {
+    if (!g || !bgr || height <= 0 || width <= 0 || downscale < 1 || g->track_pending) return -1;
+    const int oh = downscale > 1 ? height / downscale : height, ow = downscale > 1 ? width / downscale : width;
+    if (oh <= 0 || ow <= 0) return -1;
+    g->downscale = downscale;
+    if (downscale > 1 && !(g->tkey[0] == height && g->tkey[1] == width && g->tkey[2] == oh && g->tkey[3] == ow)) {
+        linear_table(ow, width, g->xt); linear_table(oh, height, g->yt);
+        g->tkey[0] = height; g->tkey[1] = width; g->tkey[2] = oh; g->tkey[3] = ow;
+    }
+    // the previous frame's corners are tracked only into a plane of the same size (GMC.apply resets otherwise)
+    const bool lk = g->have_prev_pts && g->prev_h == oh && g->prev_w == ow && !g->prev_pts.empty();
+    g->lk_pts.clear();
+    if (lk) g->lk_pts = g->prev_pts;
+    const int n = (int)(g->lk_pts.size() / 2);
+    if (g->host) {
+        g->host_frame.assign(bgr, bgr + (size_t)height * width * 3); g->hf_h = height; g->hf_w = width;
+    } else {
+        if (!lk) g->have_prev = false;                          // the device pyramid of another plane size is not a predecessor
+        const int rc = mi355_gmc_step_begin(g, bgr, height, width, oh, ow, downscale > 1 ? g->xt.data() : nullptr, downscale > 1 ? g->yt.data() : nullptr,
+                                            kQuality, n ? g->lk_pts.data() : nullptr, n, kLkWin, kLkLevels, kLkIters, kLkEps, kLkMinEig);
+        if (rc) return rc;
+    }
+    g->track_pending = true; g->t_oh = oh; g->t_ow = ow; g->t_n = n;
+    return 0;
+}
+
+extern "C" int mi355_gmc_track_finish(mi355_gmc* g, double* H_out) {
+    if (!g || !H_out || !g->track_pending) return -1;
+    g->track_pending = false;
+    const int oh = g->t_oh, ow = g->t_ow, n = g->t_n;
+    const size_t np = (size_t)oh * ow;
+    g->cur_gray.resize(np); g->eig.resize(np); g->ok.resize(np);
+    g->next_pts.assign((size_t)n * 2, 0.f); g->status.assign((size_t)n, 0);
+    if (g->host) {
+        int rc = mi355_gmc_prepare_host(g->host_frame.data(), g->hf_h, g->hf_w, oh, ow, g->downscale > 1 ? g->xt.data() : nullptr,
+                                        g->downscale > 1 ? g->yt.data() : nullptr, kQuality, g->cur_gray.data(), g->eig.data(), g->ok.data());
+        if (rc) return rc;
+        if (n > 0) {
+            rc = mi355_gmc_pyr_lk(g->prev_gray.data(), g->cur_gray.data(), oh, ow, g->lk_pts.data(), n, kLkWin, kLkLevels, kLkIters, kLkEps, kLkMinEig,
+                                  g->next_pts.data(), g->status.data());
+            if (rc) return rc;
+        }
+    } else {
+        const int rc = mi355_gmc_step_finish(g, g->cur_gray.data(), g->eig.data(), g->ok.data(), n ? g->next_pts.data() : nullptr, n ? g->status.data() : nullptr);
+        if (rc) { g->have_prev_pts = false; return rc; }
+    }
+    double H[6] = {1, 0, 0, 0, 1, 0};
+    if (n > 0) {
+        std::vector<double> src, dst;
+        for (int i = 0; i < n; ++i)
+            if (g->status[i]) {
+                src.push_back(g->lk_pts[2 * i]); src.push_back(g->lk_pts[2 * i + 1]);
+                dst.push_back(g->next_pts[2 * i]); dst.push_back(g->next_pts[2 * i + 1]);
+            }
+        const int m = (int)(src.size() / 2);
+        if (m > 4) {
+            double E[6];
+            if (mi355_gmc_affine_partial(src.data(), dst.data(), m, kRansacThr, kRansacConf, kRansacIters, 0ull, E, nullptr) == 1) {
+                std::memcpy(H, E, sizeof(H));
+                H[2] *= g->downscale; H[5] *= g->downscale;
+            }
+        }
+    }
+    // this frame becomes the previous one: its plane and its corners, strongest first
+    g->prev_pts.resize((size_t)kMaxCorners * 2);
+    const int nc = mi355_gmc_order_corners(g->eig.data(), g->ok.data(), oh, ow, kMaxCorners, g->prev_pts.data());
+    g->prev_pts.resize((size_t)std::max(nc, 0) * 2);
+    g->prev_gray.swap(g->cur_gray);
+    g->prev_h = oh; g->prev_w = ow; g->have_prev_pts = true;
+    std::memcpy(H_out, H, sizeof(H));
+    return 0;
+}
+
+// Forget the previous frame (GMC.reset_params); a pending step is collected and dropped.
+extern "C" int mi355_gmc_track_reset(mi355_gmc* g) {
+    if (!g) return -1;
+    if (g->track_pending) { double H[6]; (void)mi355_gmc_track_finish(g, H); }
+    g->have_prev_pts = false; g->prev_pts.clear(); g->prev_gray.clear(); g->prev_h = g->prev_w = 0;
+    if (!g->host) g->have_prev = false;
+    return 0;
+}
+
+// The previous frame as the object holds it (tests): plane size, number of corners; gray_out [oh * ow] and pts_out [pts_cap][2] when given.
+extern "C" int mi355_gmc_track_state(const mi355_gmc* g, int* oh, int* ow, int* n_pts, uint8_t* gray_out, float* pts_out, int pts_cap) {
+    if (!g) return -1;
+    const int n = g->have_prev_pts ? (int)(g->prev_pts.size() / 2) : 0;
+    if (oh) *oh = g->have_prev_pts ? g->prev_h : 0;
+    if (ow) *ow = g->have_prev_pts ? g->prev_w : 0;
+    if (n_pts) *n_pts = n;
+    if (gray_out && g->have_prev_pts) std::memcpy(gray_out, g->prev_gray.data(), g->prev_gray.size());
+    if (pts_out && pts_cap > 0 && n > 0) std::memcpy(pts_out, g->prev_pts.data(), (size_t)std::min(n, pts_cap) * 8);
     return 0;
 }

@@ -329,6 +329,7 @@ struct mi355_tracker {
     std::vector<TP> live, lost;
     std::vector<int> retired_ids;            // ids retired on EARLIER frames (sorted)
     std::vector<double> cost;                // scratch
+    std::vector<float> last_rows;            // the rows of the last update (a caller whose buffer was too small fetches them again)
 
     bool retired(int id) const { return std::binary_search(retired_ids.begin(), retired_ids.end(), id); }
 
@@ -467,17 +468,16 @@ struct mi355_tracker {
         }
         for (const TP& t : retired_now) retired_ids.insert(std::upper_bound(retired_ids.begin(), retired_ids.end(), t->id), t->id);
         live.swap(nl); lost.swap(nlost);
-        int m = 0;
+        last_rows.clear();
         for (const TP& t : live) {
             if (!t->confirmed) continue;
-            if (m < cap) {
-                float* o = out + (size_t)m * 8;
-                const double* s = t->mean;
-                o[0] = (float)(s[0] - s[2] / 2); o[1] = (float)(s[1] - s[3] / 2); o[2] = (float)(s[0] + s[2] / 2); o[3] = (float)(s[1] + s[3] / 2);
-                o[4] = (float)t->id; o[5] = (float)t->score; o[6] = (float)t->cls; o[7] = (float)t->idx;
-            }
-            ++m;
+            const double* s = t->mean;
+            const float o[8] = {(float)(s[0] - s[2] / 2), (float)(s[1] - s[3] / 2), (float)(s[0] + s[2] / 2), (float)(s[1] + s[3] / 2),
+                                (float)t->id, (float)t->score, (float)t->cls, (float)t->idx};
+            last_rows.insert(last_rows.end(), o, o + 8);
         }
+        const int m = (int)(last_rows.size() / 8);
+        if (cap > 0 && m > 0) std::memcpy(out, last_rows.data(), (size_t)std::min(m, cap) * 8 * sizeof(float));
         return m;
     }
 };
@@ -511,6 +511,13 @@ void mi355_tracker_destroy(mi355_tracker* t) { delete t; }
 int mi355_tracker_update(mi355_tracker* t, const float* det, int n, const double* warp, float* out_rows, int cap) {
     if (!t || n < 0 || (n > 0 && !det) || cap < 0 || (cap > 0 && !out_rows)) return -1;
     return t->update(det, n, warp, out_rows, cap);
+}
+
+int mi355_tracker_last_rows(const mi355_tracker* t, float* out_rows, int cap) {
+    if (!t || cap < 0 || (cap > 0 && !out_rows)) return -1;
+    const int m = (int)(t->last_rows.size() / 8);
+    if (cap > 0 && m > 0) std::memcpy(out_rows, t->last_rows.data(), (size_t)std::min(m, cap) * 8 * sizeof(float));
+    return m;
 }
 
 int mi355_tracker_state(const mi355_tracker* t, int* frame_id, int* ids_issued, int* n_tracked, int* n_lost) {

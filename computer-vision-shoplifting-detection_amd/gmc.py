@@ -1,45 +1,37 @@
 """Global motion compensation of BoT-SORT (``gmc_method: sparseOptFlow``, the Ultralytics default behind
-``model.track`` -- ``/root/reference/model.py:38``).
+``model.track`` -- ``/root/reference/model.py:38``) -- a thin binding of csrc/gmc_kernels.hip and csrc/gmc_host.cpp.
 
 Ultralytics' ``trackers/utils/gmc.py:GMC.apply_sparseoptflow`` estimates, per frame, the 2x3 partial-affine (similarity)
 transform of the BACKGROUND between the previous and the current frame and BoT-SORT applies it to the Kalman state of
 every track before association (``STrack.multi_gmc``), so that tracks survive camera motion.  The recipe is four OpenCV
 calls -- ``cvtColor(BGR2GRAY)``, ``resize`` to half size, ``goodFeaturesToTrack`` (Shi-Tomasi corners),
 ``calcOpticalFlowPyrLK`` (pyramidal Lucas-Kanade) and ``estimateAffinePartial2D`` (RANSAC) -- and OpenCV is not part of
-this stack.  This module implements those published algorithms from their definitions in numpy, vectorised over the
-feature points (the Lucas-Kanade loop, 98 % of the time, additionally as host C++: csrc/gmc_host.cpp, which is what runs),
-with OpenCV's default parameters as Ultralytics passes them:
+this stack.  The engine implements those published algorithms from their definitions, with OpenCV's default parameters as
+Ultralytics passes them (stated in oracle/gmc_oracle.py, the numpy restatement the tests check this module against):
 
-  * gray         : 14-bit fixed-point luma  (1868 B + 9617 G + 4899 R + 8192) >> 14
-  * half size    : INTER_LINEAR on uint8 with 11-bit coefficients (for an exact 1/2 scale: the mean of each 2x2 block)
-  * corners      : min-eigenvalue of the 3x3-block structure tensor of 3x3 Sobel gradients, quality 0.01 of the best
-                   corner, 3x3 non-maximum suppression, strongest first, at most 1000, minDistance 1
-  * optical flow : 21x21 windows, 4 pyramid levels (5-tap Gaussian pyrDown), Scharr gradients, at most 30 iterations or
-                   |step| < 0.01 px, minEigThreshold 1e-4, points that leave the image are dropped
-  * transform    : RANSAC over 2-point similarity hypotheses (reprojection threshold 3 px, confidence 0.99, at most 2000
-                   draws) + least-squares refit on the inliers
+  * on the GPU (``device=k``): frame preparation and Lucas-Kanade as HIP kernels on a stream of their own (one wavefront per
+    corner), corner ordering and RANSAC in host C++ behind them -- what ``model.track`` uses;
+  * on the host (``device=None``): every stage in host C++ (csrc/gmc_host.cpp) -- a tracker outside an engine, CPU tests.
+    Chosen by argument, never as a fallback: a HIP error in the device path raises.
 
-Host-side and sequential per video, like the tracker it serves.  PARITY UNPINNED against OpenCV (absent here): float64
-arithmetic instead of OpenCV's fixed point inside the LK loop and numpy's generator instead of cv::RNG in RANSAC, so the
-estimate agrees with OpenCV's to sub-pixel noise, not bit for bit.  Pinned by known-answer tests on synthetic frame pairs
-(tests/test_gmc.py: translation / rotation / scale recovered within 0.1 px, ids survive a panning camera).
+The state machine of ``GMC.apply`` (previous plane, previous corners) lives in the C++ object (``mi355_gmc_track_*``): a step is
+two calls from here -- :meth:`GMC.begin` (enqueue) and :meth:`GMC.apply` (collect -> matrix).  PARITY UNPINNED against OpenCV
+(absent here): float64 arithmetic instead of OpenCV's fixed point inside the LK loop and a generator of its own instead of
+cv::RNG in RANSAC, so the estimate agrees with OpenCV's to sub-pixel noise, not bit for bit.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional, Tuple
 
 import numpy as np
 
+from . import _lib
+from .tracker import warp_kalman  # noqa: F401  (STrack.multi_gmc for one track; re-exported for callers of this module)
+
 MAX_CORNERS, QUALITY_LEVEL, BLOCK_SIZE = 1000, 0.01, 3
 LK_WIN, LK_LEVELS, LK_MAX_ITERS, LK_EPS, LK_MIN_EIG = 21, 3, 30, 0.01, 1e-4
 RANSAC_THRESHOLD, RANSAC_CONFIDENCE, RANSAC_MAX_ITERS = 3.0, 0.99, 2000
-
-
-# ------------------------------------------------------------------------------------------------- image preparation
-def bgr_to_gray(frame: np.ndarray) -> np.ndarray:
-    """cv2.cvtColor(COLOR_BGR2GRAY) on uint8: 14-bit fixed-point coefficients, round to nearest."""
-    f = frame.astype(np.int32)
-    return ((f[..., 0] * 1868 + f[..., 1] * 9617 + f[..., 2] * 4899 + 8192) >> 14).astype(np.uint8)
 
 
 def _linear_coeffs(dn: int, sn: int):
@@ -54,55 +46,6 @@ def _linear_coeffs(dn: int, sn: int):
     c1 = np.rint(fx * np.float32(2048)).astype(np.int64)
     c0 = np.rint((np.float32(1) - fx) * np.float32(2048)).astype(np.int64)
     return s, c0, c1
-
-
-def resize_linear(gray: np.ndarray, dw: int, dh: int) -> np.ndarray:
-    """cv2.resize(INTER_LINEAR) of a uint8 plane (two 11-bit fixed-point passes, as the engine's letterbox kernel does)."""
-    sh, sw = gray.shape
-    xi, xa0, xa1 = _linear_coeffs(dw, sw)
-    yi, yb0, yb1 = _linear_coeffs(dh, sh)
-    src = gray.astype(np.int64)
-    hor = src[:, xi] * xa0[None, :] + src[:, np.minimum(xi + 1, sw - 1)] * xa1[None, :]
-    s0, s1 = hor[yi], hor[np.minimum(yi + 1, sh - 1)]
-    out = (((yb0[:, None] * (s0 >> 4)) >> 16) + ((yb1[:, None] * (s1 >> 4)) >> 16) + 2) >> 2
-    return np.clip(out, 0, 255).astype(np.uint8)
-
-
-def _pad101(a: np.ndarray, p: int) -> np.ndarray:
-    return np.pad(a, p, mode="reflect")                      # BORDER_REFLECT_101
-
-
-# ------------------------------------------------------------------------------------------------- Shi-Tomasi corners
-def good_features_to_track(gray: np.ndarray, max_corners: int = MAX_CORNERS, quality: float = QUALITY_LEVEL,
-                           block: int = BLOCK_SIZE) -> np.ndarray:
-    """-> float32 [n, 2] (x, y), strongest corner first."""
-    g = _pad101(gray.astype(np.float64), 1)
-    # 3x3 Sobel, scaled as cornerMinEigenVal does for 8-bit input: 1 / (2^(ksize-1) * block * 255)
-    sc = 1.0 / (4.0 * block * 255.0)
-    dx = ((g[:-2, 2:] - g[:-2, :-2]) + 2 * (g[1:-1, 2:] - g[1:-1, :-2]) + (g[2:, 2:] - g[2:, :-2])) * sc
-    dy = ((g[2:, :-2] - g[:-2, :-2]) + 2 * (g[2:, 1:-1] - g[:-2, 1:-1]) + (g[2:, 2:] - g[:-2, 2:])) * sc
-
-    def box(a):                                              # unnormalised block x block box filter
-        p = _pad101(a, block // 2)
-        h, w = a.shape
-        return sum(p[i:i + h, j:j + w] for i in range(block) for j in range(block))
-
-    a, b, c = box(dx * dx) * 0.5, box(dx * dy), box(dy * dy) * 0.5
-    eig = (a + c) - np.sqrt((a - c) * (a - c) + b * b)
-    eig = eig.astype(np.float32)
-    mx = float(eig.max()) if eig.size else 0.0
-    if mx <= 0:
-        return np.zeros((0, 2), np.float32)
-    eig = np.where(eig > mx * quality, eig, np.float32(0))   # THRESH_TOZERO
-    p = np.pad(eig, 1, mode="constant", constant_values=-np.inf)
-    h, w = eig.shape
-    dil = np.max([p[i:i + h, j:j + w] for i in range(3) for j in range(3)], axis=0)
-    ok = (eig != 0) & (eig == dil)
-    ok[0, :] = ok[-1, :] = False
-    ok[:, 0] = ok[:, -1] = False
-    ys, xs = np.nonzero(ok)
-    order = np.argsort(-eig[ys, xs], kind="stable")[:max_corners]
-    return np.stack([xs[order], ys[order]], axis=1).astype(np.float32)
 
 
 _TABLES: dict = {}
@@ -121,18 +64,13 @@ def _coeff_table(dn: int, sn: int) -> np.ndarray:
 def prepare_frame(raw_frame: np.ndarray, downscale: int = 2, device: Optional[int] = None, max_corners: int = MAX_CORNERS,
                   quality: float = QUALITY_LEVEL) -> Tuple[np.ndarray, np.ndarray]:
     """The first three OpenCV calls of ``GMC.apply_sparseoptflow`` for one BGR frame -> (gray plane at 1 / downscale, corners
-    float32 [n, 2] strongest first).  ``device=None``: the numpy statements above.  ``device=k``: csrc/gmc_kernels.hip on GPU k
-    (luma + resize in the same fixed point, the structure tensor in float64 with its sums in numpy's order, threshold and
-    non-maximum suppression), then the ordering of the kept corners here -- the same plane and the same corner list."""
+    float32 [n, 2] strongest first).  ``device=k``: csrc/gmc_kernels.hip on GPU k; ``device=None``: the same expressions as host
+    C++ (csrc/gmc_host.cpp) -- luma + resize in cv2's fixed point, the structure tensor in float64, threshold and non-maximum
+    suppression; then the ordering of the kept corners.  Both give the plane and the corner list of the numpy statement."""
+    if raw_frame.ndim != 3:
+        raise ValueError("prepare_frame takes a BGR frame [H, W, 3]")
     h, w = raw_frame.shape[:2]
     dh, dw = (h // downscale, w // downscale) if downscale > 1 else (h, w)
-    if device is None or raw_frame.ndim != 3:
-        gray = bgr_to_gray(raw_frame) if raw_frame.ndim == 3 else raw_frame
-        if downscale > 1:
-            gray = resize_linear(gray, dw, dh)
-        return gray, good_features_to_track(gray, max_corners, quality)
-    import ctypes as C
-    from . import _lib
     frame = np.ascontiguousarray(raw_frame, dtype=np.uint8)
     xt = yt = None
     if downscale > 1:
@@ -140,53 +78,24 @@ def prepare_frame(raw_frame: np.ndarray, downscale: int = 2, device: Optional[in
     gray = np.empty((dh, dw), np.uint8)
     eig = np.empty((dh, dw), np.float32)
     ok = np.empty((dh, dw), np.uint8)
-    rc = _lib.lib().mi355_gmc_prepare_device(int(device), frame.ctypes.data, h, w, dh, dw, xt.ctypes.data if xt is not None else None,
-                                             yt.ctypes.data if yt is not None else None, float(quality), gray.ctypes.data, eig.ctypes.data,
-                                             ok.ctypes.data)
+    xp, yp = (xt.ctypes.data if xt is not None else None), (yt.ctypes.data if yt is not None else None)
+    if device is None:
+        rc = _lib.lib().mi355_gmc_prepare_host(frame.ctypes.data, h, w, dh, dw, xp, yp, float(quality), gray.ctypes.data, eig.ctypes.data, ok.ctypes.data)
+    else:
+        rc = _lib.lib().mi355_gmc_prepare_device(int(device), frame.ctypes.data, h, w, dh, dw, xp, yp, float(quality), gray.ctypes.data, eig.ctypes.data,
+                                                 ok.ctypes.data)
     if rc == -2:
         raise RuntimeError(f"mi355_gmc_prepare_device: HIP error on device {device}")
     if rc != 0:
-        raise ValueError("mi355_gmc_prepare_device: bad argument")
+        raise ValueError("mi355_gmc_prepare: bad argument")
     return gray, order_corners(eig, ok, max_corners)
-
-
-# ------------------------------------------------------------------------------------------------- pyramidal Lucas-Kanade
-def _pyr_down(img: np.ndarray) -> np.ndarray:
-    """cv2.pyrDown on uint8: separable [1 4 6 4 1] / 16, reflect-101 borders, every second pixel, round to nearest."""
-    k = np.array([1, 4, 6, 4, 1], dtype=np.int64)
-    p = _pad101(img.astype(np.int64), 2)
-    h, w = img.shape
-    rows = sum(k[i] * p[:, i:i + w] for i in range(5))[:, ::2]
-    out = sum(k[i] * rows[i:i + h] for i in range(5))[::2]
-    return ((out + 128) >> 8).astype(np.uint8)
-
-
-def _scharr(img: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-    g = _pad101(img.astype(np.float64), 1)
-    dx = 3 * (g[:-2, 2:] - g[:-2, :-2]) + 10 * (g[1:-1, 2:] - g[1:-1, :-2]) + 3 * (g[2:, 2:] - g[2:, :-2])
-    dy = 3 * (g[2:, :-2] - g[:-2, :-2]) + 10 * (g[2:, 1:-1] - g[:-2, 1:-1]) + 3 * (g[2:, 2:] - g[:-2, 2:])
-    return dx, dy
-
-
-def _patches(img_pad: np.ndarray, pts: np.ndarray, pad: int, win: int) -> np.ndarray:
-    """Bilinear win x win patches whose top-left corner is pts - win // 2 (pts float64 [n, 2] in unpadded coordinates)."""
-    half = win // 2
-    x = pts[:, 0] - half + pad
-    y = pts[:, 1] - half + pad
-    ix, iy = np.floor(x).astype(np.int64), np.floor(y).astype(np.int64)
-    ax, ay = (x - ix)[:, None, None], (y - iy)[:, None, None]
-    jj = np.arange(win)
-    yy = iy[:, None, None] + jj[None, :, None]
-    xx = ix[:, None, None] + jj[None, None, :]
-    i00, i01, i10, i11 = img_pad[yy, xx], img_pad[yy, xx + 1], img_pad[yy + 1, xx], img_pad[yy + 1, xx + 1]
-    return (1 - ay) * ((1 - ax) * i00 + ax * i01) + ay * ((1 - ax) * i10 + ax * i11)
 
 
 def calc_optical_flow_pyr_lk(prev: np.ndarray, cur: np.ndarray, pts: np.ndarray, win: int = LK_WIN, levels: int = LK_LEVELS,
                              max_iters: int = LK_MAX_ITERS, eps: float = LK_EPS, min_eig: float = LK_MIN_EIG,
                              device: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
-    """The tracker the product runs.  ``device=None``: the host C++ loops of csrc/gmc_host.cpp (same arithmetic as
-    :func:`calc_optical_flow_pyr_lk_numpy`, which states the algorithm and is kept as its cross-check; 50-100x faster than it).
+    """cv2.calcOpticalFlowPyrLK as the product runs it.  ``device=None``: the host C++ loops of csrc/gmc_host.cpp (the numpy
+    statement of the algorithm is oracle/gmc_oracle.py:calc_optical_flow_pyr_lk, its cross-check in the tests).
     ``device=k``: the HIP kernels of csrc/gmc_kernels.hip on GPU k (one wavefront per point; what ``model.track`` uses: on the
     host the 1000-corner budget costs 10-27 ms per frame, thirty times the detector pass)."""
     import ctypes as C
@@ -209,144 +118,6 @@ def calc_optical_flow_pyr_lk(prev: np.ndarray, cur: np.ndarray, pts: np.ndarray,
     if rc != 0:
         raise ValueError("mi355_gmc_pyr_lk: bad argument")
     return nxt, status.astype(bool)
-
-
-def calc_optical_flow_pyr_lk_numpy(prev: np.ndarray, cur: np.ndarray, pts: np.ndarray, win: int = LK_WIN, levels: int = LK_LEVELS,
-                                   max_iters: int = LK_MAX_ITERS, eps: float = LK_EPS, min_eig: float = LK_MIN_EIG
-                                   ) -> Tuple[np.ndarray, np.ndarray]:
-    """Bouguet's pyramidal Lucas-Kanade tracker with OpenCV's defaults.  prev / cur: uint8 planes, pts float32 [n, 2] in prev.
-    -> (next points float32 [n, 2], status bool [n])."""
-    n = len(pts)
-    if n == 0:
-        return np.zeros((0, 2), np.float32), np.zeros((0,), bool)
-    pyr_p, pyr_c = [prev], [cur]
-    for _ in range(levels):
-        nh, nw = (pyr_p[-1].shape[0] + 1) // 2, (pyr_p[-1].shape[1] + 1) // 2
-        if nh <= win or nw <= win:                           # buildOpticalFlowPyramid stops at levels not larger than the window
-            break
-        pyr_p.append(_pyr_down(pyr_p[-1]))
-        pyr_c.append(_pyr_down(pyr_c[-1]))
-    top = len(pyr_p) - 1
-    pad = win + 2
-    half = win // 2
-    status = np.ones(n, bool)
-    nxt = np.zeros((n, 2), np.float64)
-    p0 = pts.astype(np.float64)
-    for lvl in range(top, -1, -1):
-        ip, ic = pyr_p[lvl], pyr_c[lvl]
-        h, w = ip.shape
-        dx, dy = _scharr(ip)
-        ipp, dxp, dyp, icp = (_pad101(a.astype(np.float64), pad) for a in (ip, dx, dy, ic))
-        pl = p0 / (1 << lvl)
-        nl = pl.copy() if lvl == top else nxt * 2.0
-        # a point whose window's corner falls outside the (window-padded) image is dropped -- at level 0 for good
-        tl = np.floor(pl - half)
-        inside = (tl[:, 0] >= -win) & (tl[:, 0] < w) & (tl[:, 1] >= -win) & (tl[:, 1] < h)
-        if lvl == 0:
-            status &= inside
-        act = np.nonzero(inside)[0]
-        if len(act):
-            plc = np.clip(pl[act], [-half, -half], [w - 1 + half, h - 1 + half])
-            I = _patches(ipp, plc, pad, win)
-            Ix = _patches(dxp, plc, pad, win)
-            Iy = _patches(dyp, plc, pad, win)
-            # OpenCV's scaling: gradients in Scharr units (32 x per-pixel slope), products times 2^-20
-            s = 1.0 / (1 << 20)
-            a11, a12, a22 = (Ix * Ix).sum((1, 2)) * s, (Ix * Iy).sum((1, 2)) * s, (Iy * Iy).sum((1, 2)) * s
-            det = a11 * a22 - a12 * a12
-            mineig = (a22 + a11 - np.sqrt((a11 - a22) ** 2 + 4 * a12 * a12)) / (2 * win * win)
-            good = (mineig >= min_eig) & (det >= np.finfo(np.float32).eps)
-            if lvl == 0:
-                status[act[~good]] = False
-            idx = act[good]
-            I, Ix, Iy = I[good], Ix[good], Iy[good]
-            a11, a12, a22, det = a11[good], a12[good], a22[good], det[good]
-            cur_pts = nl[idx].copy()
-            prev_delta = np.zeros((len(idx), 2))
-            live = np.ones(len(idx), bool)
-            for it in range(max_iters):
-                if not live.any():
-                    break
-                li = np.nonzero(live)[0]
-                q = cur_pts[li]
-                tlq = np.floor(q - half)
-                inq = (tlq[:, 0] >= -win) & (tlq[:, 0] < w) & (tlq[:, 1] >= -win) & (tlq[:, 1] < h)
-                if lvl == 0:
-                    status[idx[li[~inq]]] = False
-                live[li[~inq]] = False
-                li = li[inq]
-                if not len(li):
-                    break
-                qc = np.clip(cur_pts[li], [-half, -half], [w - 1 + half, h - 1 + half])
-                diff = (_patches(icp, qc, pad, win) - I[li]) * 32.0          # intensities carry 5 fractional bits in OpenCV
-                b1, b2 = (diff * Ix[li]).sum((1, 2)) * s, (diff * Iy[li]).sum((1, 2)) * s
-                dxy = np.stack([(a12[li] * b2 - a22[li] * b1) / det[li], (a12[li] * b1 - a11[li] * b2) / det[li]], axis=1)
-                cur_pts[li] += dxy
-                done = (dxy * dxy).sum(1) <= eps * eps
-                if it > 0:
-                    osc = (np.abs(dxy + prev_delta[li]) < 0.01).all(1) & ~done
-                    cur_pts[li[osc]] -= dxy[osc] * 0.5
-                    done |= osc
-                prev_delta[li] = dxy
-                live[li[done]] = False
-            nl[idx] = cur_pts
-        nxt = nl
-    if status.any():
-        h, w = prev.shape
-        out = (nxt[:, 0] < 0) | (nxt[:, 1] < 0) | (nxt[:, 0] >= w) | (nxt[:, 1] >= h)
-        status &= ~out
-    return nxt.astype(np.float32), status
-
-
-# ------------------------------------------------------------------------------------------------- partial affine by RANSAC
-def _similarity_from_pairs(p: np.ndarray, q: np.ndarray) -> np.ndarray:
-    """Least-squares [[a, -b, tx], [b, a, ty]] mapping p -> q (exact for two pairs)."""
-    pm, qm = p.mean(0), q.mean(0)
-    pc, qc = p - pm, q - qm
-    den = (pc * pc).sum()
-    if den <= 0:
-        return np.array([[1.0, 0.0, qm[0] - pm[0]], [0.0, 1.0, qm[1] - pm[1]]])
-    a = (pc * qc).sum() / den
-    b = (pc[:, 0] * qc[:, 1] - pc[:, 1] * qc[:, 0]).sum() / den
-    return np.array([[a, -b, qm[0] - (a * pm[0] - b * pm[1])], [b, a, qm[1] - (b * pm[0] + a * pm[1])]])
-
-
-def _same_point(a, b) -> bool:
-    """np.allclose(a, b) for two 2-vectors (rtol 1e-5, atol 1e-8) without its array machinery (30 us a call, twice per draw)"""
-    ax, ay, bx, by = float(a[0]), float(a[1]), float(b[0]), float(b[1])
-    return abs(ax - bx) <= 1e-8 + 1e-5 * abs(bx) and abs(ay - by) <= 1e-8 + 1e-5 * abs(by)
-
-
-def estimate_affine_partial_2d(src: np.ndarray, dst: np.ndarray, threshold: float = RANSAC_THRESHOLD, confidence: float = RANSAC_CONFIDENCE,
-                               max_iters: int = RANSAC_MAX_ITERS, seed: int = 0) -> Tuple[Optional[np.ndarray], np.ndarray]:
-    """cv2.estimateAffinePartial2D(src, dst, RANSAC): 4-degree-of-freedom similarity + inlier mask, or (None, zeros)."""
-    src, dst = np.asarray(src, np.float64).reshape(-1, 2), np.asarray(dst, np.float64).reshape(-1, 2)
-    n = len(src)
-    if n < 2:
-        return None, np.zeros(n, bool)
-    rng = np.random.default_rng(seed)
-    best_mask, best_count = None, 0
-    iters, it = max_iters, 0
-    thr2 = threshold * threshold
-    while it < iters:
-        it += 1
-        i, j = rng.choice(n, 2, replace=False)
-        if _same_point(src[i], src[j]) or _same_point(dst[i], dst[j]):
-            continue
-        H = _similarity_from_pairs(src[[i, j]], dst[[i, j]])
-        err = ((src @ H[:, :2].T + H[:, 2] - dst) ** 2).sum(1)
-        mask = err <= thr2
-        cnt = int(mask.sum())
-        if cnt > max(best_count, 1):
-            best_mask, best_count = mask, cnt
-            # RANSAC's adaptive stopping rule: draws needed to see an all-inlier sample with the asked confidence
-            w = cnt / n
-            denom = np.log(max(1.0 - w * w, 1e-12))
-            iters = min(iters, int(np.ceil(np.log(1.0 - confidence) / denom))) if denom < 0 else it
-    if best_mask is None or best_count < 2:
-        return None, np.zeros(n, bool)
-    H = _similarity_from_pairs(src[best_mask], dst[best_mask])          # refit on the consensus set
-    return H, best_mask
 
 
 def order_corners(eig: np.ndarray, ok: np.ndarray, max_corners: int = MAX_CORNERS) -> np.ndarray:
@@ -386,117 +157,88 @@ class GMC:
 
     ``device=k`` runs the frame preparation and the optical flow on GPU k (csrc/gmc_kernels.hip) and splits a step in two:
     :meth:`begin` enqueues it (``model.track`` does so BEFORE the detector runs on the frame, so that both share the GPU),
-    :meth:`apply` collects it -- or enqueues and collects, when nobody called ``begin`` for that frame."""
+    :meth:`apply` collects it -- or enqueues and collects, when nobody called ``begin`` for that frame.  ``device=None``: the
+    same object with every stage in host C++."""
 
     def __init__(self, method: Optional[str] = "sparseOptFlow", downscale: int = 2, device: Optional[int] = None):
-        self.device = device                   # None: everything on the host; k: frame preparation + Lucas-Kanade on GPU k
+        self.device = device
         if method in ("none", "None"):
             method = None
         if method not in (None, "sparseOptFlow"):
             raise ValueError(f"GMC method {method!r} is not implemented (sparseOptFlow, the botsort.yaml default, or None)")
         self.method, self.downscale = method, max(1, int(downscale))
-        self.prev_frame: Optional[np.ndarray] = None
-        self.prev_points: Optional[np.ndarray] = None
-        self._h = None                         # mi355_gmc object (device path), created by the first step
-        self._pending = None                   # (frame object, plane shape, points handed to Lucas-Kanade) of the enqueued step
+        self._h = None                         # mi355_gmc object, created by the first step
+        self._pending = None                   # the frame object of the enqueued step
+        self._H = np.empty((2, 3), np.float64)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h is not None and h.value:
             try:
-                from . import _lib
                 _lib.lib().mi355_gmc_destroy(h)
             except Exception:
                 pass
 
-    def reset(self) -> None:
-        self.prev_frame = self.prev_points = None
-
-    # ---- device path ---------------------------------------------------------------------------------------------------------
-    def begin(self, raw_frame: np.ndarray) -> None:
-        """Enqueue this frame's step on the GPU (no-op on the host path); :meth:`apply` of the same frame object collects it."""
-        if self.method is None or self.device is None or raw_frame is None or raw_frame.ndim != 3 or self._pending is not None:
-            return
-        import ctypes as C
-        from . import _lib
-        lib = _lib.lib()
+    def _obj(self):
         if self._h is None:
             h = C.c_void_p()
-            rc = lib.mi355_gmc_create(int(self.device), C.byref(h))
+            rc = _lib.lib().mi355_gmc_create(-1 if self.device is None else int(self.device), C.byref(h))
             if rc != 0:
                 raise RuntimeError(f"mi355_gmc_create: error {rc} on device {self.device}")
             self._h = h
-        frame = np.ascontiguousarray(raw_frame, dtype=np.uint8)
-        h0, w0 = frame.shape[:2]
-        dh, dw = (h0 // self.downscale, w0 // self.downscale) if self.downscale > 1 else (h0, w0)
-        xt = yt = None
-        if self.downscale > 1:
-            xt, yt = _coeff_table(dw, w0), _coeff_table(dh, h0)
-        pts = None
-        if self.prev_frame is not None and self.prev_points is not None and self.prev_frame.shape == (dh, dw) and len(self.prev_points):
-            pts = np.ascontiguousarray(self.prev_points, dtype=np.float32).reshape(-1, 2)
-        rc = lib.mi355_gmc_step_begin(self._h, frame.ctypes.data, h0, w0, dh, dw, xt.ctypes.data if xt is not None else None,
-                                      yt.ctypes.data if yt is not None else None, float(QUALITY_LEVEL), pts.ctypes.data if pts is not None else None,
-                                      0 if pts is None else len(pts), LK_WIN, LK_LEVELS, LK_MAX_ITERS, float(LK_EPS), float(LK_MIN_EIG))
-        if rc != 0:
-            raise RuntimeError(f"mi355_gmc_step_begin: error {rc}")
-        self._pending = (raw_frame, (dh, dw), pts)
+        return self._h
 
-    def _collect(self):
-        """-> (gray plane, corners, tracked points or None, status or None) of the enqueued step"""
-        from . import _lib
-        _, (dh, dw), pts = self._pending
+    def reset(self) -> None:
+        if self._h is not None:
+            _lib.lib().mi355_gmc_track_reset(self._h)
         self._pending = None
-        gray, eig, ok = np.empty((dh, dw), np.uint8), np.empty((dh, dw), np.float32), np.empty((dh, dw), np.uint8)
-        n = 0 if pts is None else len(pts)
-        nxt, status = np.zeros((n, 2), np.float32), np.zeros(n, np.uint8)
-        rc = _lib.lib().mi355_gmc_step_finish(self._h, gray.ctypes.data, eig.ctypes.data, ok.ctypes.data, nxt.ctypes.data if n else None,
-                                              status.ctypes.data if n else None)
-        if rc != 0:
-            raise RuntimeError(f"mi355_gmc_step_finish: error {rc}")
-        return gray, order_corners(eig, ok, MAX_CORNERS), (nxt if n else None), (status.astype(bool) if n else None)
+
+    # ---- the previous frame as the object holds it (tests) -------------------------------------------------------------------------
+    def _state(self):
+        if self._h is None:
+            return None, None
+        oh, ow, n = C.c_int(), C.c_int(), C.c_int()
+        _lib.lib().mi355_gmc_track_state(self._h, C.byref(oh), C.byref(ow), C.byref(n), None, None, 0)
+        if oh.value == 0:
+            return None, None
+        gray, pts = np.empty((oh.value, ow.value), np.uint8), np.empty((max(n.value, 1), 2), np.float32)
+        _lib.lib().mi355_gmc_track_state(self._h, None, None, None, gray.ctypes.data, pts.ctypes.data, len(pts))
+        return gray, pts[:n.value]
+
+    @property
+    def prev_frame(self) -> Optional[np.ndarray]:
+        return self._state()[0]
+
+    @property
+    def prev_points(self) -> Optional[np.ndarray]:
+        return self._state()[1]
 
     # ---- the step ------------------------------------------------------------------------------------------------------------
+    def begin(self, raw_frame: np.ndarray) -> None:
+        """Enqueue this frame's step (on the GPU for a device object); :meth:`apply` of the same frame object collects it."""
+        if self.method is None or raw_frame is None or raw_frame.ndim != 3 or self._pending is not None:
+            return
+        frame = raw_frame if (raw_frame.dtype == np.uint8 and raw_frame.flags.c_contiguous) else np.ascontiguousarray(raw_frame, dtype=np.uint8)
+        rc = _lib.lib().mi355_gmc_track_begin(self._obj(), frame.ctypes.data, frame.shape[0], frame.shape[1], self.downscale)
+        if rc == -2:
+            raise RuntimeError(f"mi355_gmc_track_begin: HIP error on device {self.device}")
+        if rc != 0:
+            raise ValueError(f"mi355_gmc_track_begin: error {rc}")
+        self._pending = raw_frame
+
     def apply(self, raw_frame: np.ndarray, detections=None) -> np.ndarray:
-        H = np.eye(2, 3)
         if self.method is None or raw_frame is None:
-            return H
-        if self.device is not None and raw_frame.ndim == 3:
-            if self._pending is not None and self._pending[0] is not raw_frame:
-                self._collect()                                      # a step enqueued for another frame: its results are stale
-                self.reset()
-            if self._pending is None:
-                self.begin(raw_frame)
-            tracked_from = self._pending[2]
-            frame, points, nxt, status = self._collect()
-            if tracked_from is None:
-                self.prev_frame, self.prev_points = frame, points
-                return H
-            prev_points = tracked_from
-        else:
-            frame, points = prepare_frame(raw_frame, self.downscale, None)
-            if self.prev_frame is None or self.prev_points is None or self.prev_frame.shape != frame.shape:
-                self.prev_frame, self.prev_points = frame.copy(), points
-                return H
-            prev_points = self.prev_points
-            nxt, status = calc_optical_flow_pyr_lk(self.prev_frame, frame, prev_points)
-        p, q = prev_points[status], nxt[status]
-        if len(p) > 4:
-            est, _ = estimate_affine_partial_2d_host(p, q)
-            if est is not None:
-                H = est
-                H[0, 2] *= self.downscale
-                H[1, 2] *= self.downscale
-        self.prev_frame, self.prev_points = frame.copy(), points
-        return H
-
-
-def warp_kalman(mean: np.ndarray, cov: np.ndarray, H: np.ndarray, R8: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
-    """``STrack.multi_gmc`` for one track: the rotation/scale block acts on every (x, y)-like pair of the state
-    (cx cy | w h | vcx vcy | vw vh), the translation on the centre only; P <- R8 P R8'.  ``R8`` = kron(I4, H[:2, :2]) may be
-    handed in by a caller that warps many tracks with one H."""
-    if R8 is None:
-        R8 = np.kron(np.eye(4), H[:2, :2])
-    m = R8 @ mean
-    m[:2] += H[:2, 2]
-    return m, R8 @ cov @ R8.T
+            return np.eye(2, 3)
+        if raw_frame.ndim != 3:
+            raise ValueError("GMC.apply takes a BGR frame [H, W, 3]")
+        if self._pending is not None and self._pending is not raw_frame:
+            self.reset()                                         # a step enqueued for another frame: its results are stale
+        if self._pending is None:
+            self.begin(raw_frame)
+        self._pending = None
+        rc = _lib.lib().mi355_gmc_track_finish(self._h, self._H.ctypes.data)
+        if rc == -2:
+            raise RuntimeError(f"mi355_gmc_track_finish: HIP error on device {self.device}")
+        if rc != 0:
+            raise ValueError(f"mi355_gmc_track_finish: error {rc}")
+        return self._H.copy()

@@ -277,6 +277,42 @@ void mi355_gmc_destroy(mi355_gmc* g);
 int  mi355_gmc_step_begin(mi355_gmc* g, const uint8_t* bgr, int height, int width, int oh, int ow, const int* xtab, const int* ytab,
                           double quality, const float* prev_pts, int n_prev, int win, int max_level, int max_iters, double eps, double min_eig);
 int  mi355_gmc_step_finish(mi355_gmc* g, uint8_t* gray_out, float* eig_out, uint8_t* ok_out, float* next_pts, uint8_t* status);
+/* ---- the tracker behind model.track (/root/reference/model.py:38-46), host C++ (csrc/tracker_host.cpp) -------------------------------------
+ * Ultralytics' default botsort.yaml tracker, one call per frame: BYTETracker.update's two-stage association on IoU cost fused with the
+ * detection score, KalmanFilterXYWH, STrack.multi_gmc's warp of the predicted states, lap.lapjv(extend_cost=True, cost_limit=thresh).
+ *   det       [n][6] float32 rows x1, y1, x2, y2, conf, cls (Results.boxes.data of the frame, conf >= 0.1 under .track)
+ *   warp      6 doubles, row-major 2 x 3: the camera motion since the previous frame (GMC.apply), or NULL = none
+ *   out_rows  [cap][8] float32 rows x1, y1, x2, y2, id, score, cls, idx (idx = row of det); the box is the Kalman state
+ * mi355_tracker_update returns the number of confirmed tracks (rows beyond cap are not written), or -1 on a bad argument.  It must be
+ * called on EVERY frame, empty ones included (frame counter, lost-track ageing against track_buffer 30). */
+typedef struct mi355_tracker mi355_tracker;
+int  mi355_tracker_create(int frame_rate, mi355_tracker** out);
+void mi355_tracker_destroy(mi355_tracker* t);
+int  mi355_tracker_update(mi355_tracker* t, const float* det, int n, const double* warp, float* out_rows, int cap);
+int  mi355_tracker_last_rows(const mi355_tracker* t, float* out_rows, int cap);   /* the rows of the last update again (count returned) */
+int  mi355_tracker_state(const mi355_tracker* t, int* frame_id, int* ids_issued, int* n_tracked, int* n_lost);
+/* which = 0: tracked (confirmed or awaiting confirmation), 1: lost.  Rows of 16 doubles: id, state (1 tracked, 2 lost, 3 removed),
+ * confirmed, frame of birth, last matched frame, score, cls, idx, mean[8] = cx cy w h + velocities.  Returns the count. */
+int  mi355_tracker_tracks(const mi355_tracker* t, int which, double* out, int cap);
+/* The pieces, for known-answer tests: the filter on (mean[8], cov[8][8] row-major) in place, and the assignment solver --
+ * lap.lapjv(cost [n_rows][n_cols], extend_cost=True, cost_limit): x_out[i] = column of row i or -1, y_out[j] = row of column j or -1. */
+int  mi355_kalman_initiate(const double* z_xywh, double* mean, double* cov);
+int  mi355_kalman_predict(double* mean, double* cov);
+int  mi355_kalman_update(double* mean, double* cov, const double* z_xywh);
+int  mi355_kalman_warp(double* mean, double* cov, const double* warp);
+int  mi355_lapjv(const double* cost, int n_rows, int n_cols, double cost_limit, int* x_out, int* y_out);
+/* Host form of mi355_gmc_prepare_device (csrc/gmc_host.cpp): the same expressions in the same order, hence the same plane and corners. */
+int  mi355_gmc_prepare_host(const uint8_t* bgr, int height, int width, int oh, int ow, const int* xtab, const int* ytab, double quality,
+                            uint8_t* gray_out, float* eig_out, uint8_t* ok_out);
+/* The whole step of GMC.apply_sparseoptflow (ultralytics/trackers/utils/gmc.py) on the object, which keeps the previous frame's plane and
+ * ordered corners: track_begin enqueues frame preparation + Lucas-Kanade from the previous frame's corners (downscale 2 is Ultralytics'),
+ * track_finish collects, orders the new corners, estimates the partial affine transform (RANSAC over the tracked pairs when more than 4
+ * survive) and writes the 2 x 3 matrix, translation in frame pixels (the identity on a first frame / too few points).  An object made by
+ * mi355_gmc_create(-1) runs every stage in host C++ and never touches a GPU.  track_state: the previous frame as held (tests). */
+int  mi355_gmc_track_begin(mi355_gmc* g, const uint8_t* bgr, int height, int width, int downscale);
+int  mi355_gmc_track_finish(mi355_gmc* g, double* H_out);
+int  mi355_gmc_track_reset(mi355_gmc* g);
+int  mi355_gmc_track_state(const mi355_gmc* g, int* oh, int* ow, int* n_pts, uint8_t* gray_out, float* pts_out, int pts_cap);
 /* The u8 stem: letterboxed BGR frames -> (x/255, RGB) -> conv k x k stride s (pad k/2, or 2 for k=6) + bias + SiLU. */
 int  mi355_op_stem(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias,
                    int cout, int k, int stride, float* y);

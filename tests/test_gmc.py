@@ -1,11 +1,14 @@
-"""Known-answer tests of BoT-SORT's global motion compensation (cvsd_amd/gmc.py; ``gmc_method: sparseOptFlow``, the
-Ultralytics default behind ``/root/reference/model.py:38``).  OpenCV is not available, so every stage is pinned against
-constructions whose answer is known: hand-computed luma values, corners of drawn squares, analytically shifted / rotated
-images, point sets with planted outliers -- and, end to end, a panning camera over static people."""
+"""Known-answer tests of BoT-SORT's global motion compensation (``gmc_method: sparseOptFlow``, the Ultralytics default behind
+``/root/reference/model.py:38``).  OpenCV is not available, so every stage is pinned against constructions whose answer is known:
+hand-computed luma values, corners of drawn squares, analytically shifted / rotated images, point sets with planted outliers --
+and, end to end, a panning camera over static people.  Two implementations go through them: the numpy restatement
+(oracle/gmc_oracle.py = ``G``, the checker) and the product's host C++ (cvsd_amd/gmc.py = ``gmc``, csrc/gmc_host.cpp), which
+must also equal the restatement stage by stage (plane and corner list bit for bit, Lucas-Kanade points to 1e-3 px)."""
 import numpy as np
 import pytest
 
 from cvsd_amd import gmc
+from oracle import gmc_oracle as G
 from cvsd_amd.tracker import BYTETracker, KalmanFilterXYWH
 
 
@@ -35,21 +38,21 @@ def _render(f, h, w, H=None):
 def test_bgr_to_gray_is_opencvs_fixed_point_luma():
     px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 100], [255, 255, 255]]], dtype=np.uint8)    # B, G, R
     # (1868 B + 9617 G + 4899 R + 8192) >> 14
-    assert gmc.bgr_to_gray(px).tolist() == [[29, 150, 76, (1868 * 10 + 9617 * 200 + 4899 * 100 + 8192) >> 14, 255]]
+    assert G.bgr_to_gray(px).tolist() == [[29, 150, 76, (1868 * 10 + 9617 * 200 + 4899 * 100 + 8192) >> 14, 255]]
 
 
 def test_half_size_linear_resize_is_the_2x2_block_mean():
     rng = np.random.default_rng(1)
     g = rng.integers(0, 256, size=(12, 16), dtype=np.uint8)
     want = (g.reshape(6, 2, 8, 2).astype(np.int64).sum((1, 3)) + 2) >> 2
-    np.testing.assert_array_equal(gmc.resize_linear(g, 8, 6), want)
+    np.testing.assert_array_equal(G.resize_linear(g, 8, 6), want)
 
 
 def test_shi_tomasi_finds_the_corners_of_drawn_squares_strongest_first():
     img = np.full((60, 80), 20, np.uint8)
     img[10:30, 15:40] = 220          # bright rectangle: corners near (15,10) (39,10) (15,29) (39,29)
     img[40:52, 50:70] = 120          # a weaker one
-    pts = gmc.good_features_to_track(img)
+    pts = G.good_features_to_track(img)
     assert 8 <= len(pts) <= 64
     strong = {(15, 10), (39, 10), (15, 29), (39, 29)}
     for x, y in pts[:4]:             # the four strongest are the bright rectangle's corners (within the 3x3 block)
@@ -57,7 +60,7 @@ def test_shi_tomasi_finds_the_corners_of_drawn_squares_strongest_first():
     found = [min(np.abs(pts - np.array(c)).sum(1)) for c in [(50, 40), (69, 40), (50, 51), (69, 51)]]
     assert max(found) <= 2           # the weaker rectangle's corners pass the 1 % quality level too
     assert (pts[:, 0] >= 1).all() and (pts[:, 0] <= 78).all()
-    assert len(gmc.good_features_to_track(np.full((40, 40), 7, np.uint8))) == 0      # flat image: no corner
+    assert len(G.good_features_to_track(np.full((40, 40), 7, np.uint8))) == 0      # flat image: no corner
 
 
 def _smooth_noise(h, w, seed, sigma=2.0):
@@ -79,7 +82,7 @@ def test_pyramidal_lk_recovers_a_known_subpixel_translation(shift):
     f = _texture(120, 160, seed=3)
     prev = _render(f, 120, 160)
     cur = _render(f, 120, 160, np.array([[1, 0, shift[0]], [0, 1, shift[1]]], float))
-    pts = gmc.good_features_to_track(prev)
+    pts = G.good_features_to_track(prev)
     pts = pts[(pts[:, 0] > 20) & (pts[:, 0] < 140) & (pts[:, 1] > 20) & (pts[:, 1] < 100)][:200]
     nxt, ok = gmc.calc_optical_flow_pyr_lk(prev, cur, pts)
     assert ok.mean() > 0.9
@@ -96,7 +99,7 @@ def test_pyramidal_lk_follows_large_integer_shifts_through_the_pyramid(shift):
     y0, x0 = 60, 80
     prev = big[y0:y0 + 180, x0:x0 + 240]
     cur = big[y0 - shift[1]:y0 - shift[1] + 180, x0 - shift[0]:x0 - shift[0] + 240]        # content moves by +shift
-    pts = gmc.good_features_to_track(prev)
+    pts = G.good_features_to_track(prev)
     pts = pts[(pts[:, 0] > 40) & (pts[:, 0] < 200) & (pts[:, 1] > 40) & (pts[:, 1] < 140)][:150]
     nxt, ok = gmc.calc_optical_flow_pyr_lk(prev, cur, pts)
     assert ok.mean() > 0.8              # windows on weak structure fail the minimum-eigenvalue test and are dropped
@@ -111,13 +114,13 @@ def test_partial_affine_ransac_ignores_outliers_and_refits_on_inliers():
     R = sc * np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
     dst = src @ R.T + t
     dst[:30] += rng.uniform(20, 60, size=(30, 2))            # a quarter of the matches are wrong (moving people)
-    H, inl = gmc.estimate_affine_partial_2d(src, dst)
+    H, inl = G.estimate_affine_partial_2d(src, dst)
     np.testing.assert_allclose(H, np.hstack([R, t[:, None]]), atol=1e-9)
     assert inl[30:].all() and not inl[:30].any()
     noisy = dst + rng.normal(0, 0.2, size=dst.shape)
-    H2, _ = gmc.estimate_affine_partial_2d(src, noisy)
+    H2, _ = G.estimate_affine_partial_2d(src, noisy)
     np.testing.assert_allclose(H2, np.hstack([R, t[:, None]]), atol=0.05)
-    assert gmc.estimate_affine_partial_2d(src[:1], dst[:1])[0] is None
+    assert G.estimate_affine_partial_2d(src[:1], dst[:1])[0] is None
 
 
 @pytest.mark.parametrize("H", [
@@ -125,7 +128,8 @@ def test_partial_affine_ransac_ignores_outliers_and_refits_on_inliers():
     np.array([[np.cos(0.02), -np.sin(0.02), 3.0], [np.sin(0.02), np.cos(0.02), 1.5]]),       # pan + 1.1 degree roll
     np.array([[1.02, 0, -2.0], [0, 1.02, 4.0]]),                                             # zoom
 ])
-def test_gmc_recovers_the_background_transform_within_a_tenth_of_a_pixel(H):
+@pytest.mark.parametrize("impl", ["product host C++", "oracle numpy"])
+def test_gmc_recovers_the_background_transform_within_a_tenth_of_a_pixel(H, impl):
     """frame pair: the texture moved by H (full-resolution pixels); GMC works at half resolution and scales the translation
     back, as Ultralytics' GMC does (downscale 2).  Error measured as the displacement error over the frame's corners."""
     h, w = 240, 320
@@ -133,7 +137,7 @@ def test_gmc_recovers_the_background_transform_within_a_tenth_of_a_pixel(H):
     g0 = _render(f, h, w)
     g1 = _render(f, h, w, H)
     bgr = lambda g: np.stack([g, g, g], -1)
-    m = gmc.GMC()
+    m = gmc.GMC() if impl.startswith("product") else G.GMC()
     np.testing.assert_array_equal(m.apply(bgr(g0)), np.eye(2, 3))          # first frame: identity
     got = m.apply(bgr(g1))
     corners = np.array([[0, 0], [w, 0], [0, h], [w, h], [w / 2, h / 2]], float)
@@ -202,14 +206,60 @@ def test_update_without_a_frame_is_the_identity_path():
         BYTETracker(gmc_method="orb")
 
 
+@pytest.mark.parametrize("shape,downscale", [((240, 320), 2), ((241, 323), 2), ((96, 128), 1), ((150, 100), 3), ((2, 40), 2), ((40, 3), 2)])
+def test_host_cpp_frame_preparation_is_the_numpy_statement_bit_for_bit(shape, downscale):
+    """csrc/gmc_host.cpp:mi355_gmc_prepare_host (what GMC(device=None) runs) against oracle/gmc_oracle.py: the gray plane byte for
+    byte, the corner list element for element -- odd sizes, no resize, a 1/3 scale, and planes with a 1-pixel dimension (reflect-101
+    of a length-1 axis: the guard the advisor asked for, on the host side)."""
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    h, w = shape
+    base = _smooth_noise(h + 8, w + 8, seed=h + w, sigma=1.5)[4:4 + h, 4:4 + w]
+    frame = np.stack([base, np.roll(base, 1, 0), np.roll(base, 1, 1)], -1).astype(np.uint8)
+    frame[rng.integers(0, h, 20), rng.integers(0, w, 20)] = rng.integers(0, 256, (20, 3))
+    gray_o, pts_o = G.prepare_frame(frame, downscale)
+    gray_p, pts_p = gmc.prepare_frame(frame, downscale, None)
+    np.testing.assert_array_equal(gray_p, gray_o)
+    np.testing.assert_array_equal(pts_p, pts_o)
+    flat = np.full((h, w, 3), 9, np.uint8)
+    assert gmc.prepare_frame(flat, downscale, None)[1].shape == (0, 2)
+
+
+def test_gmc_objects_of_both_implementations_walk_the_same_states():
+    """the product's host object (state machine in C++: mi355_gmc_track_*) and the numpy GMC over a short panning clip: the same
+    previous plane and corner list after every frame; transforms equal up to the RANSAC generators (translation < 0.05 px); a frame
+    of another size resets both; begin() of one frame followed by apply() of another drops the stale step."""
+    scene = ((_smooth_noise(200, 500, seed=31, sigma=2.0).astype(np.int32) + _smooth_noise(200, 500, seed=32, sigma=8.0)) // 2).astype(np.uint8)
+    frames = [np.stack([scene[:, 7 * k:7 * k + 320]] * 3, -1) for k in range(5)]
+    a, b = gmc.GMC(), G.GMC()
+    assert a.prev_frame is None and a.prev_points is None
+    for k, f in enumerate(frames):
+        Ha, Hb = a.apply(f), b.apply(f)
+        np.testing.assert_array_equal(a.prev_frame, b.prev_frame)
+        np.testing.assert_array_equal(a.prev_points, b.prev_points)
+        if k == 0:
+            np.testing.assert_array_equal(Ha, np.eye(2, 3))
+        else:
+            np.testing.assert_allclose(Ha, Hb, atol=0.05)
+            assert abs(Ha[0, 2] + 7.0) < 0.2 and abs(Ha[1, 2]) < 0.2
+    small = np.ascontiguousarray(frames[0][:100, :150])
+    np.testing.assert_array_equal(a.apply(small), np.eye(2, 3))
+    np.testing.assert_array_equal(b.apply(small), np.eye(2, 3))
+    assert a.prev_frame.shape == (50, 75)
+    a.begin(frames[1])                                          # enqueued for one frame ...
+    np.testing.assert_array_equal(a.apply(frames[2]), np.eye(2, 3))      # ... collected for another: stale, dropped, state reset
+    assert abs(a.apply(frames[3])[0, 2] + 7.0) < 0.2
+    a.reset()
+    assert a.prev_frame is None
+
+
 def test_host_cpp_lucas_kanade_is_the_numpy_statement_of_the_algorithm():
-    """the product runs csrc/gmc_host.cpp; gmc.calc_optical_flow_pyr_lk_numpy states the same algorithm in numpy -- same points
-    kept, same positions to float32 rounding"""
+    """the product runs csrc/gmc_host.cpp; oracle/gmc_oracle.py states the same algorithm in numpy -- same points kept, same
+    positions to float32 rounding"""
     big = ((_smooth_noise(200, 260, seed=3, sigma=2.0).astype(np.int32) + _smooth_noise(200, 260, seed=4, sigma=8.0)) // 2).astype(np.uint8)
     prev, cur = big[20:170, 30:230], big[23:173, 25:225]
-    pts = gmc.good_features_to_track(prev)[:300]
+    pts = G.good_features_to_track(prev)[:300]
     a, sa = gmc.calc_optical_flow_pyr_lk(prev, cur, pts)
-    b, sb = gmc.calc_optical_flow_pyr_lk_numpy(prev, cur, pts)
+    b, sb = G.calc_optical_flow_pyr_lk(prev, cur, pts)
     assert (sa == sb).mean() > 0.99
     both = sa & sb
     assert both.sum() > 100 and np.abs(a[both] - b[both]).max() < 1e-3
@@ -238,7 +288,7 @@ def test_host_cpp_corner_ordering_and_ransac_are_the_numpy_statements():
     bad = rng.choice(200, 50, replace=False)
     q2[bad] += rng.uniform(20, 60, size=(50, 2)) * rng.choice([-1, 1], size=(50, 2))
     H2, m2 = gmc.estimate_affine_partial_2d_host(p, q2)
-    Hn, mn = gmc.estimate_affine_partial_2d(p, q2)
+    Hn, mn = G.estimate_affine_partial_2d(p, q2)
     good = np.ones(200, bool); good[bad] = False
     np.testing.assert_array_equal(m2, good)
     np.testing.assert_array_equal(mn, good)

@@ -3,15 +3,23 @@
 from the published BoT-SORT / ByteTrack definitions (constant-velocity XYWH Kalman filter with std weights 1/20 and
 1/160, two-stage IoU association with score fusion, track_buffer 30) -- none is produced by running the tracker.
 
-Global motion compensation (``gmc_method: sparseOptFlow`` of botsort.yaml) is the IDENTITY in this build: it needs
-OpenCV's optical flow, and the UCF-Crime clips come from fixed CCTV cameras.  The CSV test at the bottom states that
-explicitly: a static person keeps exactly the measured box centre.
+Global motion compensation (``gmc_method: sparseOptFlow`` of botsort.yaml) has tests of its own (tests/test_gmc.py); here update()
+is called without a frame, or on a static scene, where it is the identity.  The CSV test at the bottom states that explicitly: a
+static person keeps exactly the measured box centre.
 """
 import numpy as np
 import pytest
 import torch
 
-from cvsd_amd.tracker import BYTETracker, KalmanFilterXYWH
+from cvsd_amd import tracker as product_tracker
+from oracle import tracker_oracle
+
+
+@pytest.fixture(params=["product: host C++ (csrc/tracker_host.cpp)", "oracle: numpy (oracle/tracker_oracle.py)"])
+def impl(request):
+    """every hand-derived answer below is asked of BOTH implementations: the product's C++ core behind the C ABI and the numpy
+    restatement that checks it"""
+    return product_tracker if request.param.startswith("product") else tracker_oracle
 
 
 def _det(*boxes):
@@ -19,7 +27,7 @@ def _det(*boxes):
     return np.asarray(boxes, dtype=np.float32).reshape(-1, 6)
 
 
-def test_kalman_initiate_predict_update_by_hand():
+def test_kalman_initiate_predict_update_by_hand(impl):
     """measurement z0 = (cx 100, cy 200, w 40, h 80).
     initiate: mean = (z0, 0,0,0,0); std = (2w/20, 2h/20, 2w/20, 2h/20, 10w/160, 10h/160, 10w/160, 10h/160)
               = (4, 8, 4, 8, 2.5, 5, 2.5, 5)  ->  P0 = diag(16, 64, 16, 64, 6.25, 25, 6.25, 25).
@@ -33,7 +41,7 @@ def test_kalman_initiate_predict_update_by_hand():
               P2[x,x] = 26.25 - 26.25^2 / 30.25 = 3.47107..., P2[x,vx] = 6.25 - 26.25 * 6.25 / 30.25 = 0.826446...,
               P2[vx,vx] = 6.3125 - 6.25^2 / 30.25 = 5.021178...
     """
-    kf = KalmanFilterXYWH()
+    kf = impl.KalmanFilterXYWH()
     mean, cov = kf.initiate(np.array([100.0, 200.0, 40.0, 80.0]))
     np.testing.assert_array_equal(mean, [100, 200, 40, 80, 0, 0, 0, 0])
     np.testing.assert_allclose(cov, np.diag([16, 64, 16, 64, 6.25, 25, 6.25, 25]), rtol=0, atol=1e-12)
@@ -52,11 +60,11 @@ def test_kalman_initiate_predict_update_by_hand():
     assert cov[1, 1] == pytest.approx(105 - 105 ** 2 / 121, abs=1e-10)
 
 
-def test_first_frame_tracks_are_reported_at_once_later_ones_after_one_confirmation():
+def test_first_frame_tracks_are_reported_at_once_later_ones_after_one_confirmation(impl):
     """ByteTrack: a track activated on frame 1 is is_activated at once; one born later is 'unconfirmed' until it is
     matched on the following frame (threshold 0.7) -- so person B, first seen on frame 2, is first REPORTED on frame 3.
     Row layout: x1,y1,x2,y2,id,score,cls,idx."""
-    tr = BYTETracker()
+    tr = impl.BYTETracker()
     a = (10, 10, 50, 90, 0.9, 0)
     b = (200, 40, 260, 160, 0.8, 0)
     out = tr.update(_det(a))
@@ -71,11 +79,11 @@ def test_first_frame_tracks_are_reported_at_once_later_ones_after_one_confirmati
     assert by_id[2][5] == pytest.approx(0.8) and by_id[1][5] == pytest.approx(0.9)
 
 
-def test_two_people_crossing_keep_their_ids():
+def test_two_people_crossing_keep_their_ids(impl):
     """A walks right (+6 px/frame), B walks left (-6 px/frame) on rows 30 px apart; they cross around frame 11.  Each
     track's constant-velocity prediction lands on its own detection (IoU ~ 1) and 12 px per frame away from the other's
     continuation, so the first association keeps A = id 1 moving right and B = id 2 moving left through the crossing."""
-    tr = BYTETracker()
+    tr = impl.BYTETracker()
     for f in range(24):
         xa, xb = 100 + 6 * f, 220 - 6 * f
         out = tr.update(_det((xa, 100, xa + 40, 180, 0.9, 0), (xb, 130, xb + 40, 210, 0.85, 0)))
@@ -87,10 +95,10 @@ def test_two_people_crossing_keep_their_ids():
     assert tr._ids_issued == 2
 
 
-def test_low_score_detection_is_used_by_the_second_association_only():
+def test_low_score_detection_is_used_by_the_second_association_only(impl):
     """Scores in (track_low_thresh 0.1, track_high_thresh 0.25) skip the first association: they can CONTINUE a tracked
     person (second stage, plain IoU distance <= 0.5) but never start a track (new_track_thresh 0.25)."""
-    tr = BYTETracker()
+    tr = impl.BYTETracker()
     box = (50, 60, 110, 200)
     tr.update(_det((*box, 0.9, 0)))
     out = tr.update(_det((*box, 0.15, 0), (300, 60, 360, 200, 0.15, 0)))
@@ -101,7 +109,7 @@ def test_low_score_detection_is_used_by_the_second_association_only():
     assert tr.update(_det((*box, 0.1, 0))).shape == (0, 8)
 
 
-def test_lost_track_is_refound_inside_the_buffer_and_retired_after_it():
+def test_lost_track_is_refound_inside_the_buffer_and_retired_after_it(impl):
     """track_buffer 30 at 30 fps: a lost track is marked Removed once frame_id - end_frame > 30.  A static person seen on
     frames 1-3 and again on frame 14 (10 empty frames: 4..13) is re-activated with the SAME id.  With 32 empty frames
     (4..35) the track is marked Removed on frame 34 (34 - 3 = 31 > 30) and has left the candidate pool by frame 36, so the
@@ -111,7 +119,7 @@ def test_lost_track_is_refound_inside_the_buffer_and_retired_after_it():
     frame (trackers/track.py:on_predict_postprocess_end)."""
     box = (120, 80, 180, 220, 0.9, 0)
     empty = np.zeros((0, 6), np.float32)
-    tr = BYTETracker()
+    tr = impl.BYTETracker()
     for _ in range(3):
         assert tr.update(_det(box))[:, 4].tolist() == [1.0]
     for _ in range(10):
@@ -120,7 +128,7 @@ def test_lost_track_is_refound_inside_the_buffer_and_retired_after_it():
     assert out[:, 4].tolist() == [1.0] and tr.frame_id == 14
     np.testing.assert_allclose(out[0, :4], box[:4], atol=0.5)
 
-    tr = BYTETracker()
+    tr = impl.BYTETracker()
     for _ in range(3):
         tr.update(_det(box))
     for k in range(32):
@@ -131,7 +139,7 @@ def test_lost_track_is_refound_inside_the_buffer_and_retired_after_it():
     out = tr.update(_det(box))
     assert out[:, 4].tolist() == [2.0]
 
-    tr = BYTETracker()
+    tr = impl.BYTETracker()
     for _ in range(3):
         tr.update(_det(box))
     for k in range(31):
@@ -139,12 +147,12 @@ def test_lost_track_is_refound_inside_the_buffer_and_retired_after_it():
     assert tr.update(_det(box))[:, 4].tolist() == [1.0]                   # frame 35: the one-frame grace of the list order
 
 
-def test_two_trackers_do_not_share_ids():
+def test_two_trackers_do_not_share_ids(impl):
     """ids belong to the tracker instance: a sweep / bridge tracker created while model.track(persist=True) is alive
     must not reset or advance the latter's counter."""
-    t1 = BYTETracker()
+    t1 = impl.BYTETracker()
     t1.update(_det((10, 10, 50, 90, 0.9, 0)))
-    t2 = BYTETracker()
+    t2 = impl.BYTETracker()
     t2.update(_det((10, 10, 50, 90, 0.9, 0), (100, 10, 150, 90, 0.9, 0)))
     out = t1.update(_det((10, 10, 50, 90, 0.9, 0), (300, 10, 350, 90, 0.9, 0)))
     assert out[:, 4].tolist() == [1.0]

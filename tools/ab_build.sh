@@ -13,6 +13,7 @@ for s in $SRCS; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 $1 -c $s.hip -o $OBJ/$s.o & pids="$pids $!"
 done
 /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 -c gmc_host.cpp -o $OBJ/gmc_host.o & pids="$pids $!"
+/opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 -c tracker_host.cpp -o $OBJ/tracker_host.o & pids="$pids $!"
 for p in $pids; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libmi355yolo_$OUT.so $(for s in $SRCS gmc_host; do echo $OBJ/$s.o; done)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libmi355yolo_$OUT.so $(for s in $SRCS gmc_host tracker_host; do echo $OBJ/$s.o; done)
 ls -la ../libmi355yolo_$OUT.so
