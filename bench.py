@@ -568,35 +568,22 @@ def main() -> None:
 def track_pipeline(n_frames: int = 160) -> dict:
     """The reference's frame loop end to end (`model.track(frame, persist=True, ...)` per frame, /root/reference/model.py:38):
     detector at batch 1 + BoT-SORT with its sparse-optical-flow motion compensation, on a synthetic 320x240 clip under a panning
-    camera (UCF-Crime's frame size).  Frames start on the host, as cv2.VideoCapture hands them over.  Three tracker set-ups: the
-    compensation's frame preparation and Lucas-Kanade step on the GPU (what model.track does), on the host (gmc_device=None: the
-    round-2/3a state), and switched off."""
+    camera (UCF-Crime's frame size).  Frames start on the host, as cv2.VideoCapture hands them over.  For YOLOv8n three tracker
+    set-ups: the compensation's frame preparation and Lucas-Kanade step on the GPU (what model.track does), on the host
+    (gmc_device=None), and switched off; for the reference's literal checkpoint family (YOLOv5mu, model.py:18) and for BASELINE config
+    4's model (YOLOv8s-pose) the product set-up.  `sweep_batch64` = the production form of the same loop (cvsd_amd/sweep.py):
+    detection batched per clip, the tracker frame by frame, frame j + 1's motion-compensation step enqueued while frame j is
+    associated."""
     import numpy as np
     from cvsd_amd import YOLO
+    from cvsd_amd.sweep import process_clip
     from cvsd_amd.tracker import BYTETracker
     from cvsd_amd.weights import build_from_state_dict
     from tools import synth
-    _, sd = synth.synthetic_checkpoint("yolov8n", seed=0)
-    model = YOLO(build_from_state_dict("yolov8n", sd), batch_chunk=1)
     rng = np.random.default_rng(5)
     base = rng.integers(0, 256, size=(256, 320 + 3 * n_frames + 16, 3), dtype=np.uint8)
     base = ((base.astype(np.uint16) + np.roll(base, 1, 0) + np.roll(base, 1, 1) + np.roll(base, (1, 1), (0, 1))) // 4).astype(np.uint8)
     frames = [np.ascontiguousarray(base[8:248, 3 * k:3 * k + 320]) for k in range(n_frames)]
-    out = {"workload": f"yolov8n model.track loop, {n_frames - 8} frames of 320x240 (host frames), conf 0.1, BoT-SORT defaults (sparseOptFlow GMC, <= 1000 corners)",
-           "unit": "frames/s"}
-    for key, make in (("gmc_on_gpu", lambda: BYTETracker(gmc_device=model.device)), ("gmc_on_host", lambda: BYTETracker(gmc_device=None)),
-                      ("gmc_off", lambda: BYTETracker(gmc_method=None))):
-        model._tracker = make()
-        for f in frames[:8]:
-            model.track(f, persist=True, conf=0.1)
-        t0 = time.perf_counter()
-        for f in frames[8:]:
-            model.track(f, persist=True, conf=0.1)
-        out[key] = round((n_frames - 8) / (time.perf_counter() - t0), 1)
-
-    # the production form of the same loop (cvsd_amd/sweep.py): detection batched per clip, the tracker frame by frame, frame j + 1's
-    # motion-compensation step enqueued while frame j is associated
-    from cvsd_amd.sweep import process_clip
 
     class Clip:
         def __init__(self, fr):
@@ -614,12 +601,36 @@ def track_pipeline(n_frames: int = 160) -> dict:
         def release(self):
             pass
 
-    big = YOLO(build_from_state_dict("yolov8n", sd), batch_chunk=64)
-    process_clip(big, Clip(frames[:64]), batch=64)
-    long_clip = frames * 4                                     # 640 frames: several 64-frame batches in flight
-    t0 = time.perf_counter()
-    process_clip(big, Clip(long_clip), batch=64)
-    out["sweep_batch64"] = round(len(long_clip) / (time.perf_counter() - t0), 1)
+    out = {"workload": f"model.track loop, {n_frames - 8} frames of 320x240 (host frames), conf 0.1, BoT-SORT defaults (sparseOptFlow GMC, <= 1000 corners); "
+                       f"tracker core in host C++ (csrc/tracker_host.cpp)", "unit": "frames/s"}
+    for name in ("yolov8n", "yolov5mu", "yolov8s-pose"):
+        _, sd = synth.synthetic_checkpoint(name, seed=0)
+        blob = build_from_state_dict(name, sd)
+        model = YOLO(blob, batch_chunk=1)
+        setups = [("gmc_on_gpu", lambda: BYTETracker(gmc_device=model.device))]
+        if name == "yolov8n":
+            setups += [("gmc_on_host", lambda: BYTETracker(gmc_device=None)), ("gmc_off", lambda: BYTETracker(gmc_method=None))]
+        res = {}
+        for key, make in setups:
+            model._tracker = make()
+            for f in frames[:8]:
+                model.track(f, persist=True, conf=0.1)
+            t0 = time.perf_counter()
+            for f in frames[8:]:
+                model.track(f, persist=True, conf=0.1)
+            res[key] = round((n_frames - 8) / (time.perf_counter() - t0), 1)
+        del model
+        big = YOLO(blob, batch_chunk=64)
+        process_clip(big, Clip(frames[:64]), batch=64)
+        long_clip = frames * 4                                     # 640 frames: several 64-frame batches in flight
+        t0 = time.perf_counter()
+        process_clip(big, Clip(long_clip), batch=64)
+        res["sweep_batch64"] = round(len(long_clip) / (time.perf_counter() - t0), 1)
+        del big
+        if name == "yolov8n":
+            out.update(res)
+        else:
+            out[name] = res
     return out
 
 

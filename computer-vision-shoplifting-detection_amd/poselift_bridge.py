@@ -54,7 +54,10 @@ def video_to_poselift(model, frames: Iterable[np.ndarray], out_path: Optional[st
     n = first_frame
 
     def detect(buf):
-        return model.predict(np.stack(buf), conf=min(conf, 0.1), **predict_kw)
+        # a video's last batch is filled up to the next power of two (sweep.pad_bucket: few planned shapes, little wasted work)
+        from .sweep import pad_bucket
+        stack = np.stack(buf + [buf[-1]] * (pad_bucket(len(buf), batch) - len(buf)))
+        return model.predict(stack, conf=min(conf, 0.1), **predict_kw)[:len(buf)]
 
     def track(fut, buf):
         nonlocal n

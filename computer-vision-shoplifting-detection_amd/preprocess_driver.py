@@ -16,6 +16,7 @@ from typing import Callable, List, Optional
 import numpy as np
 
 CAP_PROP_POS_FRAMES = 1
+CAP_PROP_FRAME_COUNT = 7          # cv2.CAP_PROP_FRAME_COUNT: what the sweep balances its ranks by
 VIDEOS_TO_PROCESS = ["Shoplifting", "Shopping"]
 
 
@@ -44,6 +45,8 @@ class NpyCapture:
         return True, f
 
     def get(self, prop):
+        if prop == CAP_PROP_FRAME_COUNT:
+            return float(len(self._frames)) if self._frames is not None else 0.0
         return float(self._pos) if prop == CAP_PROP_POS_FRAMES else 0.0
 
     def release(self):
@@ -91,6 +94,8 @@ class ImageDirCapture:
         return True, np.ascontiguousarray(rgb[..., ::-1])          # BGR, as cv2 decodes
 
     def get(self, prop):
+        if prop == CAP_PROP_FRAME_COUNT:
+            return float(len(self._files)) if self._files is not None else 0.0
         return float(self._pos) if prop == CAP_PROP_POS_FRAMES else 0.0
 
     def release(self):

@@ -1,11 +1,13 @@
-"""GPU Lucas-Kanade of BoT-SORT's motion compensation (csrc/gmc_kernels.hip) against the numpy statement of the algorithm and the
-host C++ routine, and the tracker running on it (``model.track`` hands its tracker the engine's device)."""
+"""BoT-SORT's motion compensation on the GPU (csrc/gmc_kernels.hip) against the CPU restatement in oracle/gmc_oracle.py (numpy, ``G``)
+-- and, secondarily, against the product's own host C++ -- and the tracker running on it (``model.track`` hands its tracker the
+engine's device; the tracker core's checker is oracle/tracker_oracle.py)."""
 import time
 
 import numpy as np
 import pytest
 
 from cvsd_amd import gmc
+from oracle import gmc_oracle as G
 
 pytestmark = pytest.mark.gpu
 
@@ -34,7 +36,7 @@ def test_device_lucas_kanade_is_the_numpy_statement_of_the_algorithm(shape, shif
     """same points kept, same positions to 1e-3 px (window sums are associated differently: lane-wise, then a butterfly), on even,
     odd and larger planes (the pyramid's reflect-101 borders and odd halvings included)"""
     prev, cur = _pair(shape[0], shape[1], shift[0], shift[1])
-    pts = gmc.good_features_to_track(prev)[:400]
+    pts = G.good_features_to_track(prev)[:400]
     # corners near the border too: windows that hang over the edge read reflected pixels
     edge = np.array([[1.0, 1.0], [shape[1] - 2.0, 2.0], [3.5, shape[0] - 2.5], [shape[1] - 1.0, shape[0] - 1.0]], np.float32)
     pts = np.concatenate([pts, edge])
@@ -44,7 +46,7 @@ def test_device_lucas_kanade_is_the_numpy_statement_of_the_algorithm(shape, shif
     both = sa & sh
     assert both.sum() > 100 and np.abs(a[both] - h[both]).max() < 1e-3
     if shape[0] <= 150:                                            # the numpy statement takes seconds per call
-        b, sb = gmc.calc_optical_flow_pyr_lk_numpy(prev, cur, pts[:120])
+        b, sb = G.calc_optical_flow_pyr_lk(prev, cur, pts[:120])
         ok = sa[:120] & sb
         assert (sa[:120] == sb).mean() > 0.99 and np.abs(a[:120][ok] - b[ok]).max() < 1e-3
     # the recovered motion is the planted shift
@@ -52,19 +54,23 @@ def test_device_lucas_kanade_is_the_numpy_statement_of_the_algorithm(shape, shif
     assert np.abs(np.median(d[:, 0]) - (-shift[1])) < 0.05 and np.abs(np.median(d[:, 1]) - (-shift[0])) < 0.05
 
 
-@pytest.mark.parametrize("shape,downscale", [((240, 320), 2), ((241, 323), 2), ((120, 160), 1), ((360, 640), 2), ((90, 121), 3)])
+@pytest.mark.parametrize("shape,downscale", [((240, 320), 2), ((241, 323), 2), ((120, 160), 1), ((360, 640), 2), ((90, 121), 3), ((2, 80), 2), ((80, 3), 2)])
 def test_device_frame_preparation_gives_numpys_plane_and_corner_list(shape, downscale):
     """luma, INTER_LINEAR resize, Shi-Tomasi corner map, threshold and non-maximum suppression on the GPU: the same gray plane byte
-    for byte and the same corners in the same order as the numpy statements (odd sizes, no resize, a non-integer scale)"""
+    for byte and the same corners in the same order as the numpy statement in oracle/gmc_oracle.py (odd sizes, no resize, a non-integer
+    scale, and planes with a 1-pixel dimension: reflect-101 of a length-1 axis must terminate)"""
     rng = np.random.default_rng(shape[0] + downscale)
     g = _smooth_noise(shape[0], shape[1], seed=11, sigma=1.5)
     frame = np.stack([g, np.roll(g, 3, 1), 255 - g], axis=2)
     frame = np.clip(frame.astype(np.int32) + rng.integers(-6, 7, size=frame.shape), 0, 255).astype(np.uint8)
-    gray_h, pts_h = gmc.prepare_frame(frame, downscale, None)
+    gray_h, pts_h = G.prepare_frame(frame, downscale)
     gray_d, pts_d = gmc.prepare_frame(frame, downscale, 0)
     np.testing.assert_array_equal(gray_d, gray_h)
-    assert len(pts_h) > 50
+    assert len(pts_h) > 50 or min(shape) < 8
     np.testing.assert_array_equal(pts_d, pts_h)
+    gray_c, pts_c = gmc.prepare_frame(frame, downscale, None)             # the product's host C++: the same again
+    np.testing.assert_array_equal(gray_c, gray_h)
+    np.testing.assert_array_equal(pts_c, pts_h)
     # a flat frame has no corners
     flat = np.full((shape[0], shape[1], 3), 90, np.uint8)
     assert gmc.prepare_frame(flat, downscale, 0)[1].shape == (0, 2)
@@ -80,8 +86,11 @@ def test_device_routine_rejects_bad_arguments_and_takes_empty_input():
 
 
 def test_tracker_on_the_device_keeps_the_ids_of_the_host_tracker():
-    """a panning camera over static people: the tracker whose optical flow runs on the GPU returns the boxes and ids of the host one"""
+    """a panning camera over static people: the tracker whose optical flow runs on the GPU returns the ids of the numpy tracker of
+    oracle/tracker_oracle.py (which estimates the motion with oracle/gmc_oracle.py) and the boxes and ids of the product's host form"""
     from cvsd_amd.tracker import BYTETracker
+    from oracle.tracker_oracle import BYTETracker as OracleTracker
+    ora = OracleTracker()
     h, w = 240, 320
     big = ((_smooth_noise(h + 40, w + 400, seed=7, sigma=2.0).astype(np.int32) + _smooth_noise(h + 40, w + 400, seed=8, sigma=6.0)) // 2).astype(np.uint8)
     people = np.array([[60, 60, 100, 180], [150, 40, 190, 170], [240, 80, 275, 200]], np.float32)
@@ -94,10 +103,13 @@ def test_tracker_on_the_device_keeps_the_ids_of_the_host_tracker():
                              ).astype(np.float32)
         t0 = time.perf_counter(); a = host.update(det, frame); t1 = time.perf_counter(); b = dev.update(det, frame); t2 = time.perf_counter()
         t_host += t1 - t0; t_dev += t2 - t1
-        assert a.shape == b.shape
+        c = ora.update(det, frame)
+        assert a.shape == b.shape == c.shape
         if len(a):
             np.testing.assert_array_equal(a[:, 4], b[:, 4])                  # track ids
+            np.testing.assert_array_equal(c[:, 4], b[:, 4])
             np.testing.assert_allclose(a[:, :4], b[:, :4], atol=2e-2)        # boxes after the compensated Kalman update
+            np.testing.assert_allclose(c[:, :4], b[:, :4], atol=0.25)        # the oracle's RANSAC draws from another generator
     print(f"tracker update per frame: host {t_host / 12 * 1e3:.2f} ms, device {t_dev / 12 * 1e3:.2f} ms")
 
 
@@ -107,11 +119,14 @@ def test_enqueued_steps_give_the_host_warps_and_survive_misuse():
     h, w = 240, 320
     big = ((_smooth_noise(h + 40, w + 200, seed=17, sigma=2.0).astype(np.int32) + _smooth_noise(h + 40, w + 200, seed=18, sigma=6.0)) // 2).astype(np.uint8)
     frames = [np.repeat(big[10:10 + h, 7 * k:7 * k + w, None], 3, axis=2).copy() for k in range(8)]
-    host, dev = gmc.GMC(), gmc.GMC(device=0)
+    host, dev, ora = gmc.GMC(), gmc.GMC(device=0), G.GMC()
     for k, f in enumerate(frames):
         dev.begin(f)
         a, b = host.apply(f), dev.apply(f)
         np.testing.assert_allclose(b, a, atol=1e-3)
+        np.testing.assert_allclose(b, ora.apply(f), atol=0.05)                  # numpy statement: same points, its own RANSAC generator
+        np.testing.assert_array_equal(dev.prev_frame, ora.prev_frame)
+        np.testing.assert_array_equal(dev.prev_points, ora.prev_points)
         if k:
             assert abs(a[0, 2] - (-7.0)) < 0.3 and abs(a[1, 2]) < 0.3           # the camera pans 7 px per frame
     np.testing.assert_array_equal(dev.prev_frame, host.prev_frame)

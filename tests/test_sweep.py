@@ -94,3 +94,77 @@ def test_sweep_two_ranks_equals_one(tmp_path):
     first = {c: min(i for i, cc in zip(ids, clips) if cc == c) for c in set(clips)}
     assert first[2] < first[3] < first[5]                          # person ids keep growing from clip to clip
     assert rows[0].split(",")[1] == "Shoplifting000_x264.mp4" and rows[0].endswith(",True,Shoplifting")
+
+
+def test_clips_are_balanced_by_frame_count_not_dealt_round_robin():
+    """'balance by frame count'.  UCF-Crime-like clip lengths (50 ... 2000 frames, log-uniform, 145 clips = the Shoplifting
+    + Shopping lines of Anomaly_Train.txt): the longest-processing-time assignment keeps the busiest rank within 15 % of the mean load
+    at 2 and at 8 ranks, where dealing clips k % world does not; unknown lengths count as average clips; every clip has one owner."""
+    from cvsd_amd.sweep import assign_clips
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        n = 145 if trial % 2 == 0 else int(rng.integers(9, 60))
+        lengths = np.exp(rng.uniform(np.log(50), np.log(2000), size=n)).astype(int).tolist()
+        for world in (2, 8):
+            owner = assign_clips(lengths, world)
+            assert len(owner) == n and set(owner) <= set(range(world))
+            load = np.bincount(owner, weights=lengths, minlength=world)
+            bound = 1.15 if n >= 8 * world else 1.0 + max(lengths) / load.mean()     # few clips: one clip can exceed the mean by itself
+            assert load.max() / load.mean() <= bound, (trial, world, load)
+            if n == 145 and world == 8:
+                rr = np.bincount(np.arange(n) % world, weights=lengths, minlength=world)
+                assert load.max() <= rr.max()
+    assert assign_clips([100, -1, 100, 0], 2) in ([0, 1, 1, 0], [0, 1, 0, 1], [0, 0, 1, 1], [0, 1, 1, 0])
+    assert assign_clips([], 4) == [] and assign_clips([5, 5, 5], 1) == [0, 0, 0]
+    assert assign_clips([10, 2000, 30], 2) == [1, 0, 1]                               # the long clip alone, the short ones together
+
+
+def test_sweep_of_long_and_short_clips_two_ranks_equals_one(tmp_path):
+    """clip lengths 3 ... 60 (a 20x spread), batch 4 (tails of 1, 2, 3 frames: the power-of-two padding), two ranks over gloo with the
+    frame-balanced assignment and per-clip messages to rank 0: the CSV bytes of the one-process run"""
+    import torch.multiprocessing as mp
+    root = str(tmp_path / "data")
+    os.makedirs(root)
+    rng = np.random.default_rng(1)
+    lines = []
+    for label, lens in (("Shoplifting", [60, 3, 17, 5]), ("Shopping", [9, 41, 6])):
+        os.makedirs(os.path.join(root, label), exist_ok=True)
+        for k, t in enumerate(lens):
+            name = f"{label}{k:03d}_x264"
+            clip = np.zeros((t, 240, 320, 3), np.uint8)
+            clip[:, 0, 0, 0] = (np.arange(t) * 2 + k) % 200
+            clip[:, 0, 1, 0] = (np.arange(t) + 3 * k) % 60
+            clip[:, 0, 2, 0] = rng.integers(0, 20, t)
+            np.save(os.path.join(root, label, name + ".npy"), clip)
+            lines.append(f"{label}/{name}.mp4")
+    with open(os.path.join(root, "list.txt"), "w") as f:
+        f.write("\n".join(lines))
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    _run(0, 1, 0, root, one)
+    ctx = mp.get_context("spawn")
+    port = _port()
+    procs = [ctx.Process(target=_run, args=(r, 2, port, root, two)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    for fn in ("ucf-crime_dataset.csv", "ucf-crime_dataset-normal.csv"):
+        a = open(os.path.join(one, fn), "rb").read()
+        assert a == open(os.path.join(two, fn), "rb").read() and len(a) > 0
+
+
+def test_vectorised_rows_are_the_per_box_reads_of_the_reference_loop():
+    """sweep.track_rows_xywhn against `for box in boxes: float(box.id), float(box.xywhn[0][k])` (model.py:56-64) on Results.update's
+    clipped boxes: the same float64 values"""
+    from cvsd_amd.results import Boxes, clip_boxes
+    from cvsd_amd.sweep import pad_bucket, track_rows_xywhn
+    rng = np.random.default_rng(2)
+    tracks = rng.uniform(-40, 360, size=(50, 8)).astype(np.float32)
+    tracks[:, 2:4] = tracks[:, :2] + rng.uniform(1, 120, size=(50, 2)).astype(np.float32)
+    tracks[:, 4] = np.arange(1, 51)
+    got = track_rows_xywhn(tracks, 17.0, (240, 320))
+    b = Boxes(clip_boxes(torch.as_tensor(tracks[:, :-1].copy(), dtype=torch.float32), (240, 320)), (240, 320))
+    want = [[17.0, float(box.id), *(float(box.xywhn[0][k]) for k in range(4))] for box in b]
+    np.testing.assert_array_equal(got, np.asarray(want, np.float64))
+    assert [pad_bucket(n, 64) for n in (1, 2, 3, 5, 10, 33, 63, 64)] == [1, 2, 4, 8, 16, 64, 64, 64] and pad_bucket(5, 4) == 4
