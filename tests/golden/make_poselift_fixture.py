@@ -11,6 +11,9 @@ REFERENCE'S OWN loader, ``/root/reference/shopformer/data/poselift_dataset.py:Po
                        predict() adapter
     loader           : PoseLiftDataset(data_dir, split='train' and 'test', seq_len 12, stride 6), imported from
                        /root/reference -- nothing of it is copied; only its OUTPUT tensors are stored
+    second loader    : /root/reference/shopformer_2/data/poselift_dataset.py:PoseLiftDataset with num_keypoints=18 (the synthetic
+                       neck keypoint of add_neck_keypoint, :57-91, appended to the 17 COCO joints) on the same pickle tree; its
+                       windows [C, T, 18] are stored under the "s2_" keys -- a second reference-held pin of the bridge's format
 
 Stored: the frames' seed/geometry, the bridge dict (flattened arrays), and per split the loader's (n_samples, every
 window tensor [C,T,V], labels).  tests/test_poselift_fixture.py (CPU) re-reads the bridge dict with a restated loader
@@ -32,6 +35,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 REF_LOADER = "/root/reference/shopformer/data/poselift_dataset.py"
+REF_LOADER_2 = "/root/reference/shopformer_2/data/poselift_dataset.py"
 OUT = os.path.join(ROOT, "tests", "golden", "poselift_fixture.npz")
 
 MODEL, SEED_W = "yolov8n-pose", 0
@@ -80,6 +84,9 @@ def main():
     spec = importlib.util.spec_from_file_location("ref_poselift_dataset", REF_LOADER)
     ref = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ref)                       # the reference's own module, imported where it lies
+    spec2 = importlib.util.spec_from_file_location("ref_poselift_dataset_2", REF_LOADER_2)
+    ref2 = importlib.util.module_from_spec(spec2)
+    spec2.loader.exec_module(ref2)                     # ... and the second loader (18 keypoints: COCO-17 + neck)
 
     frames = clip_frames()
     model = OracleAsModel()
@@ -102,8 +109,15 @@ def main():
                 store[key + "_n"] = np.int64(len(ds))
                 store[key + "_x"] = (torch.stack([x for x, _ in items]).numpy() if items else np.zeros((0, 3 if inc else 2, SEQ_LEN, 17), np.float32))
                 store[key + "_y"] = np.asarray([int(y) for _, y in items], np.int64)
+                ds2 = ref2.PoseLiftDataset(root, split=split, seq_len=SEQ_LEN, stride=STRIDE, num_keypoints=18, normalize=True,
+                                           include_confidence=inc)
+                items2 = [ds2[i] for i in range(len(ds2))]
+                store["s2_" + key + "_n"] = np.int64(len(ds2))
+                store["s2_" + key + "_x"] = (torch.stack([x for x, _ in items2]).numpy() if items2
+                                             else np.zeros((0, 3 if inc else 2, SEQ_LEN, 18), np.float32))
+                store["s2_" + key + "_y"] = np.asarray([int(y) for _, y in items2], np.int64)
     keys, fr, pid, bb, kp = flatten(data)
-    assert store["train_xy_n"] > 0, "no 12-frame window: the fixture would pin nothing"
+    assert store["train_xy_n"] > 0 and store["s2_train_xy_n"] > 0, "no 12-frame window: the fixture would pin nothing"
     np.savez_compressed(OUT, frame_keys=keys, row_frame=fr, row_pid=pid, row_bbox=bb, row_kpts=kp, gt=labels,
                         meta=np.asarray([N_FRAMES, H, W, SEED_F, IMGSZ, BATCH, SEQ_LEN, STRIDE], np.int64), conf=np.float64(CONF), **store)
     print(f"wrote {OUT}: {len(fr)} person rows over {len(keys)} frames; windows: "

@@ -41,7 +41,7 @@ def test_bench_line_single_gpu():
     e = par["kept_anchor_box_abs_err_px"]                       # both fp32 implementations against the float64 yardstick
     assert e["gpu_vs_f64"]["mean"] > 0 and e["torch_vs_f64"]["mean"] > 0 and e["gpu_vs_f64"]["mean"] <= 1.25 * e["torch_vs_f64"]["mean"]
     r = d["roofline"]
-    assert len(r["plan_hash"]) == 16 and r["plan_source"] in ("tuned", "file", "memory") and "traffic_source" in r
+    assert len(r["plan_hash"]) == 16 and r["plan_source"] in ("tuned", "file", "cache", "memory") and "traffic_source" in r
     assert r["traffic"] is None                                 # a PMC figure is only quoted for the exact workload it was collected on
     assert "configs" not in d and "host_fed_value" not in d   # those ride on the default headline workload only
 

@@ -138,6 +138,10 @@ def test_engine_to_poselift_reproduces_the_reference_loader_fixture(v8n_pose):
         x, y = windows(data, seq_len=seq_len, stride=stride, include_confidence=True, frame_labels=labels)
         np.testing.assert_array_equal(x, fix[f"{split}_xyc_x"])
         np.testing.assert_array_equal(y, fix[f"{split}_xyc_y"])
+        # ... and the windows the second reference loader (shopformer_2, 18 keypoints with the synthetic neck) made of the same tree
+        x18, y18 = windows(data, seq_len=seq_len, stride=stride, include_confidence=True, frame_labels=labels, num_keypoints=18)
+        np.testing.assert_array_equal(x18, fix[f"s2_{split}_xyc_x"])
+        np.testing.assert_array_equal(y18, fix[f"s2_{split}_xyc_y"])
 
 
 def test_plan_file_tune_path_and_load_path(v8n, tmp_path, monkeypatch):
@@ -158,9 +162,23 @@ def test_plan_file_tune_path_and_load_path(v8n, tmp_path, monkeypatch):
     m2 = YOLO.from_state_dict("yolov8n", v8n[1], batch_chunk=2)
     r2 = m2.predict(frames, imgsz=160)
     i2 = m2.plan_info()
-    assert i2["plan_source"] == "file" and i2["plan_hash"] == i1["plan_hash"] and os.stat(files[0]).st_mtime_ns == stamp
+    assert i2["plan_source"] == "cache" and i2["plan_hash"] == i1["plan_hash"] and os.stat(files[0]).st_mtime_ns == stamp
     for a, b in zip(r1, r2):
         np.testing.assert_array_equal(a.boxes.data.numpy(), b.boxes.data.numpy())
+    # a SHIPPED plan directory (mi355_opts.plan_dir; the package's plans/ by default) is looked up before the machine's cache and is
+    # never written to: the same launches (same hash), source "file"
+    import shutil
+    shipped = tmp_path / "shipped"
+    shipped.mkdir()
+    shutil.copy(files[0], shipped)
+    monkeypatch.setenv("MI355_PLAN_CACHE", str(tmp_path / "empty_cache"))
+    m4 = YOLO.from_state_dict("yolov8n", v8n[1], batch_chunk=2, plan_dir=str(shipped))
+    r4 = m4.predict(frames, imgsz=160)
+    i4 = m4.plan_info()
+    assert i4["plan_source"] == "file" and i4["plan_hash"] == i1["plan_hash"] and not glob.glob(str(tmp_path / "empty_cache" / "*.plan"))
+    for a, b in zip(r1, r4):
+        np.testing.assert_array_equal(a.boxes.data.numpy(), b.boxes.data.numpy())
+    monkeypatch.setenv("MI355_PLAN_CACHE", str(tmp_path))
     # a stale file (other fingerprint: another build, GPU or knob setting) is not trusted
     lines = open(files[0]).read().split("\n")
     head = lines[0].split()

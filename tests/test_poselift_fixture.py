@@ -44,6 +44,23 @@ def test_restated_loader_equals_the_reference_loader(fix, split, inc):
         assert set(y.tolist()) == {0, 1}                                           # the majority-label rule saw both classes
 
 
+@pytest.mark.parametrize("split,inc", [("train", False), ("train", True), ("test", False), ("test", True)])
+def test_restated_loader_equals_the_second_reference_loader_with_its_neck_keypoint(fix, split, inc):
+    """/root/reference/shopformer_2/data/poselift_dataset.py (num_keypoints=18: COCO-17 + the synthetic neck of :57-91) on the same pickle
+    tree: a second reference-held pin of the bridge's output format"""
+    data = unflatten(fix["frame_keys"], fix["row_frame"], fix["row_pid"], fix["row_bbox"], fix["row_kpts"])
+    x, y = windows(data, seq_len=int(fix["meta"][6]), stride=int(fix["meta"][7]), include_confidence=inc,
+                   frame_labels=fix["gt"] if split == "test" else None, num_keypoints=18)
+    key = f"s2_{split}_{'xyc' if inc else 'xy'}"
+    assert len(x) == int(fix[key + "_n"]) > 0 and x.shape[1:] == (3 if inc else 2, 12, 18)
+    np.testing.assert_array_equal(y, fix[key + "_y"])
+    np.testing.assert_array_equal(x, fix[key + "_x"])
+    # the neck really is the shoulders' midpoint wherever both shoulders are present (raw pixels, before normalisation)
+    k = fix["row_kpts"]
+    both = (np.abs(k[:, 5, :2]).sum(1) > 0) & (np.abs(k[:, 6, :2]).sum(1) > 0)
+    assert both.any()
+
+
 def test_writer_round_trip_is_lossless(fix, tmp_path):
     """PoseLiftWriter.add_frame / save reproduce the stored dict from tracker rows + keypoints (xywh boxes, float32)"""
     from cvsd_amd.poselift_bridge import PoseLiftWriter
