@@ -253,6 +253,9 @@ def test_track_call_of_the_reference(v8n):
     ("yolov5mu", 1, 240, 320, 640),         # the reference's literal model AND call: YOLO("yolov5mu.pt") on a 320x240 UCF-Crime
                                             # frame, batch 1 (/root/reference/model.py:18,38): resize to 480x640, C3 x2/4/6/2
     ("yolov8n", 1, 1280, 1280, 1280),       # 33600 anchors: > 32768 sort keys, global-memory bitonic path
+    ("yolov8s-pose", 8, 640, 640, 640),     # BASELINE config 4 as stated: its model, its per-GPU batch, full resolution
+    ("yolov8m", 1, 640, 640, 640),          # config 5's model at full 640 resolution (fp32 engine)
+    ("yolov8m", 2, 1280, 1280, 1280),       # config 5's model, frame size and per-GPU batch in the canonical fp32 arithmetic
 ])
 def test_bit_exact_other_models_and_sizes(name, n, h, w, imgsz):
     from oracle import det
