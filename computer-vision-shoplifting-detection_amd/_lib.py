@@ -119,6 +119,7 @@ SIGNATURES = {
                                          C.c_void_p]),
     "mi355_gmc_track_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mi355_gmc_track_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi355_gmc_track_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mi355_gmc_track_reset": (C.c_int, [C.c_void_p]),
     "mi355_gmc_track_state": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, C.c_void_p, C.c_void_p, C.c_int]),
     "mi355_op_stem": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,

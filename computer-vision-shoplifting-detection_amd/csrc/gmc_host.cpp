@@ -243,8 +243,12 @@ extern "C" int mi355_gmc_order_corners(const float* eig, const uint8_t* ok, int 
     std::vector<int> idx;
     const int n = height * width;
     for (int i = 0; i < n; ++i) if (ok[i]) idx.push_back(i);
-    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return eig[a] > eig[b]; });
+    // strongest first, raster order among equals = a strict total order on (strength, index): only the first max_corners places are
+    // sorted (a textured frame keeps several thousand corners; the tracker uses a thousand)
+    auto before = [&](int a, int b) { return eig[a] > eig[b] || (eig[a] == eig[b] && a < b); };
     const int m = std::min((int)idx.size(), max_corners);
+    if (m < (int)idx.size()) std::partial_sort(idx.begin(), idx.begin() + m, idx.end(), before);
+    else std::sort(idx.begin(), idx.end(), before);
     for (int k = 0; k < m; ++k) { xy_out[2 * k] = (float)(idx[k] % width); xy_out[2 * k + 1] = (float)(idx[k] / width); }
     return m;
 }

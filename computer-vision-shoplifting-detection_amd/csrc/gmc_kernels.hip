@@ -16,6 +16,7 @@
 #include <cstring>
 #include <limits>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -32,9 +33,11 @@ __device__ __forceinline__ int reflect101(int i, int n) {          // BORDER_REF
 }
 
 // cv2.pyrDown on uint8: separable [1 4 6 4 1] / 16 twice, reflect-101 borders, every second pixel, (s + 128) >> 8
-__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* src, int h, int w, uint8_t* dst, int nh, int nw) {
+// blockIdx.y = frame of a batch (mi355_gmc_track_batch): planes of consecutive frames are `fstride` bytes apart (0 for one frame)
+__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* src, int h, int w, uint8_t* dst, int nh, int nw, size_t fstride = 0) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= nh * nw) return;
+    src += blockIdx.y * fstride; dst += blockIdx.y * fstride;
     const int y = idx / nw, x = idx - y * nw;
     const int k[5] = {1, 4, 6, 4, 1};
     int s = 0;
@@ -55,6 +58,9 @@ struct LkArgs {
     int top, n, win, max_iters, width, height;
     double eps2, min_eig;
     const float* pts; float* next; uint8_t* status;
+    // batch of frame pairs (blockIdx.y = pair; mi355_gmc_track_batch): pair p tracks n_arr[p] points from plane p into plane p + 1, the
+    // planes of consecutive frames `pair_stride` bytes apart, its points / results at p * max_pts.  One pair: all zero / null.
+    size_t pair_stride; int max_pts; const int* n_arr;
 };
 
 // Sum over the 64 lanes, the same bits in every lane.  Four row_shr steps inside each row of 16 lanes (data-parallel-primitive moves:
@@ -212,7 +218,15 @@ __global__ __launch_bounds__(64 * kLkWaves) void lk_kernel(LkArgs a) {
     __shared__ LkScratch scratch[kLkWaves];
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * kLkWaves + (threadIdx.x >> 6);
-    if (i >= a.n) return;
+    const int pair = blockIdx.y;
+    if (i >= (a.n_arr ? a.n_arr[pair] : a.n)) return;
+    {
+        const size_t po = (size_t)pair * a.pair_stride;
+#pragma unroll
+        for (int l = 0; l < kMaxLevels; ++l) { a.prev[l] += po; a.cur[l] += po; }
+        const size_t qo = (size_t)pair * (size_t)a.max_pts;
+        a.pts += 2 * qo; a.next += 2 * qo; a.status += qo;
+    }
     uint8_t* reg = region[threadIdx.x >> 6];
     LkScratch& sc = scratch[threadIdx.x >> 6];
     const int win = a.win, half = win / 2, W2 = win * win;
@@ -312,9 +326,10 @@ __global__ __launch_bounds__(64 * kLkWaves) void lk_kernel(LkArgs a) {
 // gray = (1868 B + 9617 G + 4899 R + 8192) >> 14, then INTER_LINEAR with 11-bit coefficients (tables from the host: source index,
 // two taps per output column / row), both passes in cv2's fixed point: ((c0 * (h0 >> 4)) >> 16) + ((c1 * (h1 >> 4)) >> 16) + 2) >> 2
 __global__ __launch_bounds__(256) void gray_resize_kernel(const uint8_t* bgr, int H, int W, const int* xtab, const int* ytab, uint8_t* out, int oh, int ow,
-                                                          int resize) {
+                                                          int resize, size_t in_fstride = 0, size_t out_fstride = 0) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= oh * ow) return;
+    bgr += blockIdx.y * in_fstride; out += blockIdx.y * out_fstride;
     const int y = idx / ow, x = idx - y * ow;
     auto gray = [&](int yy, int xx) {
         const uint8_t* p = bgr + ((size_t)yy * W + xx) * 3;
@@ -333,8 +348,9 @@ __global__ __launch_bounds__(256) void gray_resize_kernel(const uint8_t* bgr, in
 
 // cornerMinEigenVal (3x3 Sobel scaled by 1 / (4 * block * 255), block x block box sums of the products, smaller eigenvalue) as
 // float32, and its maximum over the plane (non-negative floats order like their bit patterns)
-__global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* g, int h, int w, float* eig, unsigned* max_bits) {
+__global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* g, int h, int w, float* eig, unsigned* max_bits, size_t g_fstride = 0) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    g += blockIdx.y * g_fstride; eig += (size_t)blockIdx.y * h * w; max_bits += blockIdx.y;
     float e = 0.f;
     if (idx < h * w) {
         const int y = idx / w, x = idx - y * w;
@@ -368,6 +384,7 @@ __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* g, int h, i
 __global__ __launch_bounds__(256) void corner_mask_kernel(const float* eig, int h, int w, const unsigned* max_bits, double quality, uint8_t* ok) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= h * w) return;
+    eig += (size_t)blockIdx.y * h * w; ok += (size_t)blockIdx.y * h * w; max_bits += blockIdx.y;
     const int y = idx / w, x = idx - y * w;
     const float mx = __uint_as_float(*max_bits);
     const float thr = (float)((double)mx * quality);
@@ -553,6 +570,9 @@ struct mi355_gmc {
     int prev_h = 0, prev_w = 0; bool have_prev_pts = false;
     bool track_pending = false; int t_oh = 0, t_ow = 0, t_n = 0;
     std::vector<uint8_t> host_frame; int hf_h = 0, hf_w = 0;   // host object: the frame of the pending step
+    // mi355_gmc_track_batch: device buffers of one batch (grow-only) and their pinned mirror
+    uint8_t* d_batch = nullptr; size_t batch_cap = 0;
+    uint8_t* h_batch = nullptr; size_t hbatch_cap = 0;
 };
 
 extern "C" int mi355_gmc_create(int device, mi355_gmc** out) {
@@ -581,6 +601,8 @@ extern "C" void mi355_gmc_destroy(mi355_gmc* g) {
     for (int i = 0; i < 2; ++i) if (g->d_pyr[i]) (void)hipFree(g->d_pyr[i]);
     if (g->d_pts) (void)hipFree(g->d_pts); if (g->d_next) (void)hipFree(g->d_next); if (g->d_status) (void)hipFree(g->d_status);
     if (g->h_pin) (void)hipHostFree(g->h_pin);
+    if (g->d_batch) (void)hipFree(g->d_batch);
+    if (g->h_batch) (void)hipHostFree(g->h_batch);
     delete g;
 }
 
@@ -797,6 +819,166 @@ extern "C" int mi355_gmc_track_finish(mi355_gmc* g, double* H_out) {
     g->prev_gray.swap(g->cur_gray);
     g->prev_h = oh; g->prev_w = ow; g->have_prev_pts = true;
     std::memcpy(H_out, H, sizeof(H));
+    return 0;
+}
+
+// n consecutive frames of one video in ONE call (a batched sweep holds the frames of a detector batch before the tracker needs their
+// warps): the frame preparation of all n frames as one set of launches, the corner ordering of the n planes on host threads, the
+// Lucas-Kanade tracking of all n frame pairs as ONE launch (n x <= 1000 wavefronts instead of n dependent launches of <= 1000), RANSAC
+// per pair on host threads.  Same kernels, same arithmetic and the same state transitions as n track_begin / track_finish steps --
+// H_out [n][6] equals theirs bit for bit -- at a fraction of the latency: a step's kernels are latency-bound (148 us for 1000 corners
+// whatever the chip could do beside them).  Continues from / leaves behind the object's previous frame.  frames: n pointers to BGR
+// frames of height x width.  Host objects run the n steps one after the other.
+extern "C" int mi355_gmc_track_batch(mi355_gmc* g, const uint8_t* const* frames, int n, int height, int width, int downscale, double* H_out) {
+    if (!g || !frames || n <= 0 || height <= 0 || width <= 0 || downscale < 1 || !H_out || g->track_pending) return -1;
+    for (int f = 0; f < n; ++f) if (!frames[f]) return -1;
+    if (g->host) {
+        for (int f = 0; f < n; ++f) {
+            int rc = mi355_gmc_track_begin(g, frames[f], height, width, downscale); if (rc) return rc;
+            rc = mi355_gmc_track_finish(g, H_out + 6 * f); if (rc) return rc;
+        }
+        return 0;
+    }
+    const int oh = downscale > 1 ? height / downscale : height, ow = downscale > 1 ? width / downscale : width;
+    if (oh <= 0 || ow <= 0) return -1;
+    GCHK(hipSetDevice(g->device));
+    g->downscale = downscale;
+    const int resize = downscale > 1;
+    if (resize && !(g->tkey[0] == height && g->tkey[1] == width && g->tkey[2] == oh && g->tkey[3] == ow)) {
+        linear_table(ow, width, g->xt); linear_table(oh, height, g->yt);
+        g->tkey[0] = height; g->tkey[1] = width; g->tkey[2] = oh; g->tkey[3] = ow;
+    }
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t nb = (size_t)height * width * 3, np = (size_t)oh * ow;
+    int hs[kMaxLevels], ws[kMaxLevels], levels = 1;
+    hs[0] = oh; ws[0] = ow;
+    for (int l = 0; l < kLkLevels && levels < kMaxLevels; ++l) {
+        const int nh = (hs[levels - 1] + 1) / 2, nw = (ws[levels - 1] + 1) / 2;
+        if (nh <= kLkWin || nw <= kLkWin) break;
+        hs[levels] = nh; ws[levels] = nw; ++levels;
+    }
+    size_t off[kMaxLevels], pyr_bytes = 0;
+    for (int l = 0; l < levels; ++l) { off[l] = pyr_bytes; pyr_bytes += al((size_t)hs[l] * ws[l]); }
+    // does the object's previous frame precede frames[0]?  (same plane size, corners known, its pyramid on the device)
+    const bool cont = g->have_prev_pts && g->prev_h == oh && g->prev_w == ow && g->have_prev && g->ph == oh && g->pw == ow && g->pyr_cap >= pyr_bytes;
+    // device: [frames n x nb | pyramids (n + 1) x pyr_bytes | eig n x np x 4 | ok n x np | x table | y table | max n x 4 | pts n x kMaxCorners x 8 |
+    //          next (same) | status n x kMaxCorners | counts n x 4]
+    const size_t fstride = al(nb);
+    const size_t o_pyr = (size_t)n * fstride, o_eig = o_pyr + (size_t)(n + 1) * pyr_bytes, o_ok = o_eig + al((size_t)n * np * 4), o_xt = o_ok + al((size_t)n * np),
+                 o_yt = o_xt + al((size_t)ow * 12), o_max = o_yt + al((size_t)oh * 12), o_pts = o_max + al((size_t)n * 4),
+                 o_next = o_pts + al((size_t)n * kMaxCorners * 8), o_st = o_next + al((size_t)n * kMaxCorners * 8), o_cnt = o_st + al((size_t)n * kMaxCorners),
+                 d_total = o_cnt + al((size_t)n * 4);
+    if (g->batch_cap < d_total) {
+        if (g->d_batch) (void)hipFree(g->d_batch);
+        g->d_batch = nullptr; g->batch_cap = 0;
+        GCHK(hipMalloc(&g->d_batch, d_total)); g->batch_cap = d_total;
+    }
+    // pinned: [frames | tables | eig | ok | pts | next | status | counts | last gray]
+    const size_t p_xt = (size_t)n * fstride, p_yt = p_xt + al((size_t)ow * 12), p_eig = p_yt + al((size_t)oh * 12), p_ok = p_eig + al((size_t)n * np * 4),
+                 p_pts = p_ok + al((size_t)n * np), p_next = p_pts + al((size_t)n * kMaxCorners * 8), p_st = p_next + al((size_t)n * kMaxCorners * 8),
+                 p_cnt = p_st + al((size_t)n * kMaxCorners), p_gray = p_cnt + al((size_t)n * 4), h_total = p_gray + al(np);
+    if (g->hbatch_cap < h_total) {
+        if (g->h_batch) (void)hipHostFree(g->h_batch);
+        g->h_batch = nullptr; g->hbatch_cap = 0;
+        GCHK(hipHostMalloc(&g->h_batch, h_total)); g->hbatch_cap = h_total;
+    }
+    uint8_t* D = g->d_batch; uint8_t* P = g->h_batch;
+    for (int f = 0; f < n; ++f) std::memcpy(P + (size_t)f * fstride, frames[f], nb);
+    GCHK(hipMemcpyAsync(D, P, (size_t)n * fstride, hipMemcpyHostToDevice, g->stream));
+    if (resize) {
+        std::memcpy(P + p_xt, g->xt.data(), (size_t)ow * 12); std::memcpy(P + p_yt, g->yt.data(), (size_t)oh * 12);
+        GCHK(hipMemcpyAsync(D + o_xt, P + p_xt, (size_t)ow * 12, hipMemcpyHostToDevice, g->stream));
+        GCHK(hipMemcpyAsync(D + o_yt, P + p_yt, (size_t)oh * 12, hipMemcpyHostToDevice, g->stream));
+    }
+    GCHK(hipMemsetAsync(D + o_max, 0, (size_t)n * 4, g->stream));
+    if (cont) GCHK(hipMemcpyAsync(D + o_pyr, g->d_pyr[g->slot], pyr_bytes, hipMemcpyDeviceToDevice, g->stream));   // slot 0 = the previous frame's pyramid
+    uint8_t* pyr1 = D + o_pyr + pyr_bytes;                     // frame f's pyramid at pyr1 + f * pyr_bytes
+    const unsigned blocks = (unsigned)((np + 255) / 256);
+    hipLaunchKernelGGL(gray_resize_kernel, dim3(blocks, n), dim3(256), 0, g->stream, D, height, width, (const int*)(D + o_xt), (const int*)(D + o_yt),
+                       pyr1 + off[0], oh, ow, resize, fstride, pyr_bytes);
+    hipLaunchKernelGGL(min_eig_kernel, dim3(blocks, n), dim3(256), 0, g->stream, pyr1 + off[0], oh, ow, (float*)(D + o_eig), (unsigned*)(D + o_max), pyr_bytes);
+    hipLaunchKernelGGL(corner_mask_kernel, dim3(blocks, n), dim3(256), 0, g->stream, (const float*)(D + o_eig), oh, ow, (const unsigned*)(D + o_max), kQuality,
+                       D + o_ok);
+    for (int l = 1; l < levels; ++l) {
+        const int npx = hs[l] * ws[l];
+        hipLaunchKernelGGL(pyr_down_kernel, dim3((npx + 255) / 256, n), dim3(256), 0, g->stream, pyr1 + off[l - 1], hs[l - 1], ws[l - 1], pyr1 + off[l], hs[l],
+                           ws[l], pyr_bytes);
+    }
+    GCHK(hipGetLastError());
+    GCHK(hipMemcpyAsync(P + p_eig, D + o_eig, (size_t)n * np * 4, hipMemcpyDeviceToHost, g->stream));
+    GCHK(hipMemcpyAsync(P + p_ok, D + o_ok, (size_t)n * np, hipMemcpyDeviceToHost, g->stream));
+    GCHK(hipMemcpyAsync(P + p_gray, pyr1 + (size_t)(n - 1) * pyr_bytes + off[0], np, hipMemcpyDeviceToHost, g->stream));
+    if (hipStreamSynchronize(g->stream) != hipSuccess) { (void)hipGetLastError(); g->have_prev = false; g->have_prev_pts = false; return -2; }
+    // corners of every frame, strongest first (host threads); pair f tracks the corners of frame f - 1 (f = 0: the object's previous frame)
+    std::vector<std::vector<float>> corners(n);
+    std::vector<int> ncorn(n, 0);
+    const int nthreads = std::max(1, std::min(std::min(8, n), (int)std::thread::hardware_concurrency()));
+    auto parallel = [&](auto&& body) {
+        if (nthreads <= 1) { for (int f = 0; f < n; ++f) body(f); return; }
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t) th.emplace_back([&, t] { for (int f = t; f < n; f += nthreads) body(f); });
+        for (auto& t : th) t.join();
+    };
+    parallel([&](int f) {
+        corners[f].resize((size_t)kMaxCorners * 2);
+        ncorn[f] = std::max(0, mi355_gmc_order_corners((const float*)(P + p_eig) + (size_t)f * np, P + p_ok + (size_t)f * np, oh, ow, kMaxCorners, corners[f].data()));
+        corners[f].resize((size_t)ncorn[f] * 2);
+    });
+    int* cnt = (int*)(P + p_cnt);
+    float* hp = (float*)(P + p_pts);
+    int any = 0;
+    for (int f = 0; f < n; ++f) {
+        const std::vector<float>* src = f == 0 ? (cont && !g->prev_pts.empty() ? &g->prev_pts : nullptr) : &corners[f - 1];
+        cnt[f] = src ? (int)(src->size() / 2) : 0;
+        if (cnt[f]) std::memcpy(hp + (size_t)f * kMaxCorners * 2, src->data(), src->size() * sizeof(float));
+        any |= cnt[f];
+    }
+    if (any) {
+        GCHK(hipMemcpyAsync(D + o_pts, P + p_pts, (size_t)n * kMaxCorners * 8, hipMemcpyHostToDevice, g->stream));
+        GCHK(hipMemcpyAsync(D + o_cnt, P + p_cnt, (size_t)n * 4, hipMemcpyHostToDevice, g->stream));
+        LkArgs a{};
+        for (int l = 0; l < levels; ++l) { a.prev[l] = D + o_pyr + off[l]; a.cur[l] = pyr1 + off[l]; a.h[l] = hs[l]; a.w[l] = ws[l]; }
+        a.top = levels - 1; a.n = 0; a.win = kLkWin; a.max_iters = kLkIters; a.width = ow; a.height = oh;
+        a.eps2 = kLkEps * kLkEps; a.min_eig = kLkMinEig;
+        a.pts = (const float*)(D + o_pts); a.next = (float*)(D + o_next); a.status = D + o_st;
+        a.pair_stride = pyr_bytes; a.max_pts = kMaxCorners; a.n_arr = (const int*)(D + o_cnt);
+        hipLaunchKernelGGL(lk_kernel, dim3((kMaxCorners + kLkWaves - 1) / kLkWaves, n), dim3(64 * kLkWaves), 0, g->stream, a);
+        GCHK(hipGetLastError());
+        GCHK(hipMemcpyAsync(P + p_next, D + o_next, (size_t)n * kMaxCorners * 8, hipMemcpyDeviceToHost, g->stream));
+        GCHK(hipMemcpyAsync(P + p_st, D + o_st, (size_t)n * kMaxCorners, hipMemcpyDeviceToHost, g->stream));
+    }
+    // the last frame's pyramid becomes the object's previous one (the per-frame entry points continue from it)
+    if (g->pyr_cap < pyr_bytes) {
+        for (int i = 0; i < 2; ++i) { if (g->d_pyr[i]) (void)hipFree(g->d_pyr[i]); g->d_pyr[i] = nullptr; }
+        g->pyr_cap = 0;
+        GCHK(hipMalloc(&g->d_pyr[0], pyr_bytes)); GCHK(hipMalloc(&g->d_pyr[1], pyr_bytes)); g->pyr_cap = pyr_bytes;
+    }
+    GCHK(hipMemcpyAsync(g->d_pyr[g->slot], pyr1 + (size_t)(n - 1) * pyr_bytes, pyr_bytes, hipMemcpyDeviceToDevice, g->stream));
+    if (hipStreamSynchronize(g->stream) != hipSuccess) { (void)hipGetLastError(); g->have_prev = false; g->have_prev_pts = false; return -2; }
+    g->have_prev = true; g->ph = oh; g->pw = ow;
+    const float* hn = (const float*)(P + p_next);
+    const uint8_t* hst = P + p_st;
+    parallel([&](int f) {
+        double* H = H_out + 6 * f;
+        H[0] = 1; H[1] = 0; H[2] = 0; H[3] = 0; H[4] = 1; H[5] = 0;
+        const int m0 = cnt[f];
+        if (!m0) return;
+        std::vector<double> src, dst;
+        const float* p0 = hp + (size_t)f * kMaxCorners * 2; const float* p1 = hn + (size_t)f * kMaxCorners * 2; const uint8_t* st = hst + (size_t)f * kMaxCorners;
+        for (int i = 0; i < m0; ++i)
+            if (st[i]) { src.push_back(p0[2 * i]); src.push_back(p0[2 * i + 1]); dst.push_back(p1[2 * i]); dst.push_back(p1[2 * i + 1]); }
+        const int m = (int)(src.size() / 2);
+        if (m > 4) {
+            double E[6];
+            if (mi355_gmc_affine_partial(src.data(), dst.data(), m, kRansacThr, kRansacConf, kRansacIters, 0ull, E, nullptr) == 1) {
+                std::memcpy(H, E, sizeof(E));
+                H[2] *= downscale; H[5] *= downscale;
+            }
+        }
+    });
+    g->prev_pts = corners[n - 1];
+    g->prev_gray.assign(P + p_gray, P + p_gray + np);
+    g->prev_h = oh; g->prev_w = ow; g->have_prev_pts = true;
     return 0;
 }
 

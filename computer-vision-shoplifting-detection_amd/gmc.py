@@ -226,6 +226,29 @@ class GMC:
             raise ValueError(f"mi355_gmc_track_begin: error {rc}")
         self._pending = raw_frame
 
+    def apply_batch(self, frames) -> np.ndarray:
+        """The warps of n consecutive frames of one video in ONE call -> float64 [n, 2, 3], continuing from the object's previous frame:
+        all n frame preparations as one set of launches and all n Lucas-Kanade steps as one launch on the GPU, corner ordering and
+        RANSAC on host threads (``mi355_gmc_track_batch``).  Bit for bit what n ``apply`` calls return -- for a caller that holds the
+        frames of a detector batch before the tracker needs their warps (``sweep.process_clip``), at a fraction of the latency."""
+        frames = list(frames)
+        n = len(frames)
+        if self.method is None or n == 0:
+            return np.tile(np.eye(2, 3), (n, 1, 1))
+        if any(f.ndim != 3 or f.shape != frames[0].shape for f in frames):
+            raise ValueError("apply_batch takes BGR frames [H, W, 3] of one size")
+        if self._pending is not None:
+            self.reset()                                         # a step enqueued for a single frame: stale
+        keep = [f if (f.dtype == np.uint8 and f.flags.c_contiguous) else np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
+        ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in keep])
+        H = np.empty((n, 2, 3), np.float64)
+        rc = _lib.lib().mi355_gmc_track_batch(self._obj(), ptrs, n, keep[0].shape[0], keep[0].shape[1], self.downscale, H.ctypes.data)
+        if rc == -2:
+            raise RuntimeError(f"mi355_gmc_track_batch: HIP error on device {self.device}")
+        if rc != 0:
+            raise ValueError(f"mi355_gmc_track_batch: error {rc}")
+        return H
+
     def apply(self, raw_frame: np.ndarray, detections=None) -> np.ndarray:
         if self.method is None or raw_frame is None:
             return np.eye(2, 3)

@@ -61,10 +61,9 @@ def video_to_poselift(model, frames: Iterable[np.ndarray], out_path: Optional[st
 
     def track(fut, buf):
         nonlocal n
-        tracker.gmc.begin(buf[0])                                     # device path only
-        for j, (frame, res) in enumerate(zip(buf, fut.result())):
-            # every frame, empty ones too (frame_id / lost-track ageing); the next frame's motion-compensation step is enqueued ahead
-            rows = tracker.update(res.boxes.data.numpy(), frame, next_img=buf[j + 1] if j + 1 < len(buf) else None)
+        warps = tracker.gmc.apply_batch(buf) if tracker.gmc.method is not None else [None] * len(buf)     # the batch's warps in one call
+        for res, warp in zip(fut.result(), warps):
+            rows = tracker.update(res.boxes.data.numpy(), warp=warp)   # every frame, empty ones too (frame_id / lost-track ageing)
             if len(rows):
                 rows = clip_boxes(rows.copy(), res.orig_shape)  # Results.update clips the track boxes to the frame
                 idx = rows[:, -1].astype(int)

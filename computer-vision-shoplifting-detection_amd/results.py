@@ -38,7 +38,14 @@ class _BaseTensor:
         return len(self.data)
 
     def __getitem__(self, idx):
-        return self.__class__(self.data[idx], self.orig_shape)
+        d = self.data
+        if isinstance(d, torch.Tensor) and not d.is_cuda and isinstance(idx, (np.ndarray, list, torch.Tensor)):
+            # row selection through a numpy view of the same memory: torch's CPU advanced-indexing kernel costs 10-60 MILLIseconds
+            # for a [300, 17, 3] tensor once its OpenMP pool has many threads (measured: 54 ms at 8 threads against 10 us at 1),
+            # which made `res[idx]` of the tracker callback the slowest step of a pose model's frame loop
+            ix = idx.numpy() if isinstance(idx, torch.Tensor) else np.asarray(idx)
+            return self.__class__(torch.from_numpy(np.ascontiguousarray(d.numpy()[ix])), self.orig_shape)
+        return self.__class__(d[idx], self.orig_shape)
 
 
 def _clone(x):
@@ -126,8 +133,12 @@ class Keypoints(_BaseTensor):
         if keypoints.ndim == 2:
             keypoints = keypoints[None, :]
         if keypoints.shape[2] == 3:
-            mask = keypoints[..., 2] < 0.5
-            keypoints[..., :2][mask] = 0
+            if isinstance(keypoints, torch.Tensor) and not keypoints.is_cuda:
+                k = keypoints.numpy()                         # same memory (see _BaseTensor.__getitem__ on torch's CPU indexing kernels)
+                k[..., :2][k[..., 2] < 0.5] = 0
+            else:
+                mask = keypoints[..., 2] < 0.5
+                keypoints[..., :2][mask] = 0
         super().__init__(keypoints, orig_shape)
         self.has_visible = self.data.shape[-1] == 3
 

@@ -94,9 +94,9 @@ def process_clip(model, cap, batch: int = 64, conf: float = 0.1, classes=(0,), *
     """All tracked boxes of one clip: array [rows, 6] = frame number (1-based), local track id, xywhn (centre x, centre y,
     w, h).  Detection is batched; the tracker sees the frames one by one, in order (model.py:38 semantics).
 
-    Three things run side by side: the detector pass of batch k + 1 (a worker thread inside the engine's C call), the tracker's
-    association of batch k on this thread, and -- on a GPU stream of its own -- the motion-compensation step of the NEXT frame,
-    enqueued as soon as the current frame's has been collected."""
+    Two things run side by side: the detector pass of batch k + 1 (a worker thread inside the engine's C call) and, on this thread, the
+    tracker's work on batch k -- first the motion compensation of all its frames as ONE batched GPU step on a stream of its own, then
+    the association frame by frame (host C++)."""
     from concurrent.futures import ThreadPoolExecutor
     from .tracker import BYTETracker
     tracker = BYTETracker(gmc_device=getattr(model, "device", None))     # motion compensation on the engine's GPU (csrc/gmc_kernels.hip)
@@ -108,11 +108,12 @@ def process_clip(model, cap, batch: int = 64, conf: float = 0.1, classes=(0,), *
         return model.predict(stack, conf=conf, classes=list(classes), **predict_kw)[:len(buf)]
 
     def track(fut, nums, buf):
-        tracker.gmc.begin(buf[0])                              # no-op when the previous batch's last frame already enqueued it
+        # the camera-motion warps of the whole batch in one call (all frame preparations as one set of launches, all Lucas-Kanade steps
+        # as one launch: gmc.apply_batch), beside the detector pass of the NEXT batch; then the association, frame by frame
+        warps = tracker.gmc.apply_batch(buf) if tracker.gmc.method is not None else [None] * len(buf)
         results = fut.result()
-        for j, (n, frame, res) in enumerate(zip(nums, buf, results)):
-            # every frame, empty ones too (frame_id / lost-track ageing); frame j + 1's step is enqueued while frame j is associated
-            tracks = tracker.update(res.boxes.data.numpy(), frame, next_img=buf[j + 1] if j + 1 < len(buf) else None)
+        for n, res, warp in zip(nums, results, warps):
+            tracks = tracker.update(res.boxes.data.numpy(), warp=warp)      # every frame, empty ones too (frame_id / lost-track ageing)
             if len(tracks):                                    # `if not boxes.is_track: return` otherwise (model.py:45)
                 blocks.append(track_rows_xywhn(tracks, n, res.orig_shape))
 

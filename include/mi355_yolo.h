@@ -311,6 +311,10 @@ int  mi355_gmc_prepare_host(const uint8_t* bgr, int height, int width, int oh, i
  * mi355_gmc_create(-1) runs every stage in host C++ and never touches a GPU.  track_state: the previous frame as held (tests). */
 int  mi355_gmc_track_begin(mi355_gmc* g, const uint8_t* bgr, int height, int width, int downscale);
 int  mi355_gmc_track_finish(mi355_gmc* g, double* H_out);
+/* n consecutive frames in ONE call (a batched sweep holds a detector batch's frames before the tracker needs their warps): all n frame
+ * preparations as one set of launches, all n Lucas-Kanade steps as one launch, corner ordering and RANSAC on host threads.  H_out [n][6] is
+ * bit for bit what n track_begin / track_finish steps return; the object's previous frame is continued from and left behind. */
+int  mi355_gmc_track_batch(mi355_gmc* g, const uint8_t* const* frames, int n, int height, int width, int downscale, double* H_out);
 int  mi355_gmc_track_reset(mi355_gmc* g);
 int  mi355_gmc_track_state(const mi355_gmc* g, int* oh, int* ow, int* n_pts, uint8_t* gray_out, float* pts_out, int pts_cap);
 /* The u8 stem: letterboxed BGR frames -> (x/255, RGB) -> conv k x k stride s (pad k/2, or 2 for k=6) + bias + SiLU. */

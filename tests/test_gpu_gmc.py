@@ -190,3 +190,34 @@ def test_frame_size_change_restarts_the_sequence():
     host.apply(b)
     b2 = np.repeat(g[2:202, 3:303, None], 3, axis=2).copy()
     np.testing.assert_allclose(dev.apply(b2), host.apply(b2), atol=2e-3)
+
+
+@pytest.mark.parametrize("shape", [(240, 320), (97, 131), (24, 40)])
+def test_batched_steps_are_the_single_steps_bit_for_bit(shape):
+    """mi355_gmc_track_batch (all frame preparations of a detector batch as one set of launches, all Lucas-Kanade steps as one launch)
+    against the frame-by-frame entry points on the same GPU: the same warps, bit for bit, and the same state afterwards -- across
+    two batches of different length, and when single steps and batches alternate on one object"""
+    h, w = shape
+    g = _smooth_noise(h + 40, w + 120, seed=41, sigma=1.8)
+    frames = [np.repeat(g[3 + (k % 4):3 + (k % 4) + h, 5 * k:5 * k + w, None], 3, axis=2).copy() for k in range(13)]
+    one, bat, mix = gmc.GMC(device=0), gmc.GMC(device=0), gmc.GMC(device=0)
+    want = np.stack([one.apply(f) for f in frames])
+    got = np.concatenate([bat.apply_batch(frames[:8]), bat.apply_batch(frames[8:])])
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(bat.prev_frame, one.prev_frame)
+    np.testing.assert_array_equal(bat.prev_points, one.prev_points)
+    m = [mix.apply(frames[0]), *mix.apply_batch(frames[1:6]), mix.apply(frames[6]), mix.apply(frames[7]), *mix.apply_batch(frames[8:9]), *mix.apply_batch(frames[9:])]
+    np.testing.assert_array_equal(np.stack(m), want)
+    if min(shape) > 60:
+        assert np.abs(want[1:, 0, 2] + 5.0).max() < 0.3                      # the camera pans 5 px per frame
+    # the host object runs a batch as single steps
+    host = gmc.GMC()
+    np.testing.assert_allclose(host.apply_batch(frames[:4]), want[:4], atol=2e-3)
+    # another frame size restarts the sequence inside the batched entry point too
+    small = [np.ascontiguousarray(f[:h // 2 * 2 - 10, :w - 20]) for f in frames[:3]]
+    w2 = bat.apply_batch(small)
+    np.testing.assert_array_equal(w2[0], np.eye(2, 3))
+    ref = gmc.GMC(device=0)
+    np.testing.assert_array_equal(w2, np.stack([ref.apply(f) for f in small]))
+    with pytest.raises(ValueError):
+        bat.apply_batch([frames[0], small[0]])
