@@ -316,7 +316,14 @@ int create_impl(const uint8_t* blob, size_t nbytes, int device_id, const mi355_o
     if (const char* e = getenv("MI355_FAST_ACT")) h->fast_act = atoi(e) != 0 && !h->half;
     if (const char* e = getenv("MI355_PLAN_DIR")) h->plan_dir = e;
     if (const char* e = getenv("MI355_PLAN_CACHE")) { h->plan_cache_on = std::strcmp(e, "0") != 0 && *e; if (h->plan_cache_on) h->plan_cache_dir = e; }
-    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    {
+        // the detector's own stream at the highest priority the device offers: work that shares the GPU with it (the tracker's motion
+        // compensation on a low-priority stream, csrc/gmc_kernels.hip) must not delay its chain of dependent launches
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        static const bool high_prio = !(getenv("MI355_ENGINE_PRIO") && atoi(getenv("MI355_ENGINE_PRIO")) == 0);
+        HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, high_prio ? greatest : 0));
+    }
     HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
     HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -587,7 +588,13 @@ extern "C" int mi355_gmc_create(int device, mi355_gmc** out) {
     GCHK(hipSetDevice(device));
     mi355_gmc* g = new mi355_gmc();
     g->device = device;
-    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); delete g; return -2; }
+    // The step runs BESIDE the detector pass (model.track enqueues it first): on a stream of the LOWEST priority, so that where both
+    // compete for a CU the detector's dependent launches go first and the motion compensation fills what they leave idle
+    // (MI355_GMC_PRIO=0: default priority; A/B in tools/track_prio_ab.sh)
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    static const bool low_prio = !(getenv("MI355_GMC_PRIO") && atoi(getenv("MI355_GMC_PRIO")) == 0);
+    if (hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, low_prio ? least : 0) != hipSuccess) { (void)hipGetLastError(); delete g; return -2; }
     *out = g;
     return 0;
 }
