@@ -78,6 +78,38 @@ def conv_flops_per_frame(model_name: str, size: int) -> float:
     return 2.0 * sum(c.cout * c.cin * c.k * c.k * (640 // c.stride_div) ** 2 for c in pg.convs if c.cin != 3) * (size / 640.0) ** 2
 
 
+def conv_bytes_per_frame(model_name: str, size: int, elem_bytes: int) -> float:
+    """SURVEY 8(d)'s layerwise bytes of the same convs conv_flops_per_frame counts: every conv reads its input once and writes its
+    output once (the compulsory HBM traffic when each layer round-trips; fused launches move less), activations only."""
+    from cvsd_amd.graph import build_program, parse_model_name
+    pg = build_program(*parse_model_name(model_name))
+    px = lambda sd: (640 // sd) ** 2
+    return float(sum(elem_bytes * (c.cin * px(c.stride_div) * c.s * c.s + c.cout * px(c.stride_div)) for c in pg.convs if c.cin != 3)) * (size / 640.0) ** 2
+
+
+def weight_bytes(model_name: str, elem_bytes: int) -> float:
+    from cvsd_amd.graph import build_program, parse_model_name
+    pg = build_program(*parse_model_name(model_name))
+    return float(sum(elem_bytes * c.cout * c.cin * c.k * c.k for c in pg.convs if c.cin != 3))
+
+
+HBM_PEAK_TBS = 8.0              # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def roofline_fractions(model_name: str, size: int, batch: int, half: bool, conv_ms: float) -> dict:
+    """BOTH fractions of the conv stack -- algorithmic FLOPs over the matrix peak of the arithmetic type, algorithmic
+    (layerwise) bytes over the HBM peak -- from the same HIP-event conv time; `bound` names the larger one."""
+    es = 2 if half else 4
+    flops = conv_flops_per_frame(model_name, size) * batch
+    nbytes = conv_bytes_per_frame(model_name, size, es) * batch + weight_bytes(model_name, es)
+    t = conv_ms * 1e-3
+    ff = flops / t / 1e12 / (F16_PEAK_TFLOPS if half else FP32_PEAK_TFLOPS)
+    hf = nbytes / t / 1e12 / HBM_PEAK_TBS
+    return {"flops_frac": round(ff, 4), "hbm_frac": round(hf, 4), "bound": "mfma" if ff >= hf else "hbm",
+            "algorithmic_gflop_per_step": round(flops / 1e9, 2), "algorithmic_gb_per_step": round(nbytes / 1e9, 3),
+            "algorithmic_gb_per_s": round(nbytes / t / 1e9, 1)}
+
+
 def profile_convs(model, frames, size: int, steps: int = 3):
     """Per-kind device time of a step from HIP events on the engine's own stream (profiling mode: one in-order stream)."""
     model.set_profiling(True)
@@ -267,6 +299,7 @@ def measure_config(model_name: str, size: int, batch: int, half: bool, steps: in
     out = {"workload": f"{model_name} {size}x{size} batch {batch}" + (" half=True" if half else ""), "dtype": "f16" if half else "f32",
            "value": round(batch * steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
            "roofline": {"achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                        **roofline_fractions(model_name, size, batch, half, conv_ms),
                         "launches_per_step": launches, "plan_hash": plan["plan_hash"], "plan_source": plan["plan_source"]},
            "activation_bytes": plan["activation_bytes"]}
     del frames, model
@@ -495,17 +528,18 @@ def main() -> None:
     # HBM section); the figure collected on this exact workload is kept under profiles/ and quoted ONLY with its source
     # named and only while the launch sequence it was collected on has the same length as this run's -- else null.
     traffic, traffic_source = None, None
-    for tname in ("r03_conv_traffic.json", "r02_conv_traffic.json"):
-        tpath = os.path.join(ROOT, "profiles", tname)
-        if os.path.exists(tpath) and args.model == "yolov8n" and args.size == 640 and B == 512 and args.chunk == 512 and not args.half:
-            with open(tpath) as f:
-                tj = json.load(f)
-            if int(tj.get("launches_per_step", -1)) == launches:
-                traffic = tj["hbm_bytes_per_launch_avg"]
-                traffic_source = f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate run of this command; not measured in this process)"
-            else:
-                traffic_source = f"profiles/{tname} not quoted: collected on {tj.get('launches_per_step')} launches per step, this run has {launches}"
-            break
+    plan = model.plan_info()
+    tag = "cfg5" if (args.half and args.model == "yolov8m" and args.size == 1280 and B == 16) else "v1" if (args.model == "yolov8n" and args.size == 640 and B == 512 and not args.half) else None
+    tpath = os.path.join(ROOT, "profiles", f"r04_{tag}_conv_traffic.json") if tag and args.chunk == B else None
+    if tpath and os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("plan_hash") == plan["plan_hash"]:
+            traffic = tj["hbm_bytes_per_launch_avg"]
+            traffic_source = (f"profiles/r04_{tag}_conv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command, FETCH doubled per "
+                              f"the guide's gfx950 correction; same launch plans: plan_hash {plan['plan_hash']}; not measured in this process)")
+        else:
+            traffic_source = f"profiles/r04_{tag}_conv_traffic.json not quoted: collected on plan_hash {tj.get('plan_hash')}, this run has {plan['plan_hash']}"
     peak = F16_PEAK_TFLOPS if args.half else FP32_PEAK_TFLOPS
     line = {
         "metric": f"frames/s @{args.size}x{args.size}" + (" (half=True engine: diagnostic)" if args.half else "") + (" (HOST frames, PCIe-inclusive: diagnostic)" if args.host_frames else ""), "value": round(fps, 1), "unit": "frames/s", "n_gpus": world,
@@ -520,12 +554,12 @@ def main() -> None:
         "roofline": {"bound": "mfma", "kernel": ("conv_igemm_f16 + conv1x1_pipe_f16" if args.half else "conv_igemm_f32 + conv1x1_pipe_f32 + conv1x1_stream_f32") + " (every conv launch of a step)",
                      "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
+                     **{k: v for k, v in roofline_fractions(args.model, args.size, B, args.half, conv_ms).items() if k != "bound"},
                      "launches_per_step": launches,
                      "flop_per_launch_avg": conv_flops_frame * B / max(launches, 1)},
         "device_ms_per_step": {k: round(v, 3) for k, v in kinds.items()},
     }
     headline_default = (args.model == "yolov8n" and args.size == 640 and B == 512 and not args.half and not args.host_frames)
-    plan = model.plan_info()
     line["roofline"]["plan_hash"], line["roofline"]["plan_source"] = plan["plan_hash"], plan["plan_source"]
     line["config"]["activation_bytes_per_gpu"] = plan["activation_bytes"]
     want_cpu = world == 1 and not args.no_cpu_baseline and not args.half
