@@ -85,7 +85,11 @@ std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int ci
     // fp32: 0 = the default (4, or 3 with CT 5); 2 and 1 for latency-bound launches.
     std::vector<int> pt_sel = {0};
     static const int small_k_pt2 = env_int("MI355_SMALLK_PT2", 1);
-    if (half) pt_sel.push_back(8);
+    // fp16, thin launches (the default wave tile makes fewer than ~1.5 waves per SIMD: config 5 at its stated 2 frames per GPU): also
+    // 2 and 1 pixel tiles per wave -- more, shorter waves (conv_f16_small.hip)
+    static const int f16_small = env_int("MI355_F16_SMALL_PT", 1);
+    const bool thin_f16 = half && f16_small && blocks_default < 1536 && !f2_cin16;
+    if (half) { pt_sel.push_back(8); if (thin_f16) { pt_sel.push_back(2); pt_sel.push_back(1); } }
     else if (latency_bound) { pt_sel.push_back(2); pt_sel.push_back(1); }
     else if (small_k_pt2 && ks == 3 && cin16 * ks * ks <= 288) pt_sel.push_back(2);   // short K loops: staging + epilogue weigh as much
                                                                                      // as the MFMAs, so more (narrower) waves per SIMD pay
@@ -94,7 +98,7 @@ std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int ci
         for (int CT = 1; CT <= 5; ++CT) {
             if (CT > max_ct || WC < min_wc) continue;
             if (PTsel == 8 && CT > 4) continue;
-            if (!half && PTsel != 0 && CT > 2) continue;               // small wave tiles exist for CT 1 and 2
+            if (PTsel != 0 && PTsel != 8 && CT > 2) continue;          // small wave tiles exist for CT 1 and 2
             const int WP = 4 / WC, PT = PTsel ? PTsel : (CT == 5 ? 3 : 4), P = WP * PT * 16;
             // cout groups: G = 1 (one group; more cout tiles = more blocks along grid.y, each staging the input again) or, when
             // all of Cin is staged at once, G = as many groups as cover every cout tile from ONE staged input (fp32 kernels)
@@ -218,7 +222,7 @@ std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int ci
                 }
     }
     std::sort(out.begin(), out.end(), [](const Plan& a, const Plan& b) { return a.cost < b.cost; });
-    if (latency_bound) {
+    if (latency_bound || thin_f16) {
         // the latency model is crude: let the timed top-N hold both families, best of each alternating
         std::vector<Plan> big, small, merged;
         for (const Plan& p : out) ((p.PT == 0 || p.PT >= 4) && p.version != 6 && !(p.version == 3 && p.buf_floats == 1) ? big : small).push_back(p);
@@ -270,6 +274,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     }
     KernelFn fn = half ? (p.version == 4 ? (KernelFn)pick_conv_pipe_f16(p.CT, p.WP, (c.Cin + 1) / 2 <= p.ck, p.ck > 64)
                           : p.f2 ? (KernelFn)pick_conv_fused_f16(c.stride, p.CT, p.WP, p.PT)
+                                 : (p.version == 1 && (p.PT == 1 || p.PT == 2)) ? (KernelFn)pick_conv_small_f16(c.k, c.stride, p.CT, p.WP, p.PT)
                                  : (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.version == 3 ? p.buf_floats : p.PT))
                        : (p.version == 3 ? pick_f32_stream(p.CT, p.buf_floats)
                           : p.version == 4 ? pick_f32_pipe(p.CT, p.WP, c.Cin <= p.ck, p.ck, p.PT)

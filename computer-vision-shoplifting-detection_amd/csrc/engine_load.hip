@@ -317,11 +317,11 @@ int create_impl(const uint8_t* blob, size_t nbytes, int device_id, const mi355_o
     if (const char* e = getenv("MI355_PLAN_DIR")) h->plan_dir = e;
     if (const char* e = getenv("MI355_PLAN_CACHE")) { h->plan_cache_on = std::strcmp(e, "0") != 0 && *e; if (h->plan_cache_on) h->plan_cache_dir = e; }
     {
-        // the detector's own stream at the highest priority the device offers: work that shares the GPU with it (the tracker's motion
-        // compensation on a low-priority stream, csrc/gmc_kernels.hip) must not delay its chain of dependent launches
+        // default priority; MI355_ENGINE_PRIO=1 asks for the highest the device offers (A/B only: measured no gain for the detector when
+        // the tracker's motion compensation shares the GPU, tools/track_prio_ab.sh)
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        static const bool high_prio = !(getenv("MI355_ENGINE_PRIO") && atoi(getenv("MI355_ENGINE_PRIO")) == 0);
+        static const bool high_prio = getenv("MI355_ENGINE_PRIO") && atoi(getenv("MI355_ENGINE_PRIO")) == 1;
         HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, high_prio ? greatest : 0));
     }
     HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));

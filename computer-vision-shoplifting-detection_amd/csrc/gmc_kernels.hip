@@ -588,12 +588,13 @@ extern "C" int mi355_gmc_create(int device, mi355_gmc** out) {
     GCHK(hipSetDevice(device));
     mi355_gmc* g = new mi355_gmc();
     g->device = device;
-    // The step runs BESIDE the detector pass (model.track enqueues it first): on a stream of the LOWEST priority, so that where both
-    // compete for a CU the detector's dependent launches go first and the motion compensation fills what they leave idle
-    // (MI355_GMC_PRIO=0: default priority; A/B in tools/track_prio_ab.sh)
+    // The step runs BESIDE the detector pass (model.track enqueues it first), on a stream of its own at the default priority.  Measured
+    // (tools/track_prio_ab.sh, round 4): giving this stream the LOWEST and the detector's the HIGHEST priority does not speed the detector
+    // up (637-644 us per frame either way) and delays the collect (119-139 -> 163-171 us): 805-838 -> 863-893 us per frame.
+    // MI355_GMC_PRIO=1 asks for the lowest priority (A/B only).
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    static const bool low_prio = !(getenv("MI355_GMC_PRIO") && atoi(getenv("MI355_GMC_PRIO")) == 0);
+    static const bool low_prio = getenv("MI355_GMC_PRIO") && atoi(getenv("MI355_GMC_PRIO")) == 1;
     if (hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, low_prio ? least : 0) != hipSuccess) { (void)hipGetLastError(); delete g; return -2; }
     *out = g;
     return 0;
