@@ -45,6 +45,9 @@ EXTRA_CONFIGS = [
     ("yolov8m", 1280, 16, True, 10, 3, 0.0),
     # the reference's literal checkpoint family and call: YOLO("./models/yolov5mu.pt") + .track() = batch 1 (/root/reference/model.py:18,38)
     ("yolov5mu", 640, 1, False, 300, 50, 8.0),
+    # the headline workload with mi355_opts.fast_act = 1 (opt-in tolerance mode: SiLU on v_exp_f32 / v_rcp_f32 instead of the canonical,
+    # bit-reproducible form); never the headline value -- its own entry with its own parity block
+    ("yolov8n", 640, 512, False, 12, 3, 0.0, True),
 ]
 HEADLINE_CPU_BUDGET_S = 18.0
 
@@ -275,14 +278,14 @@ def cpu_reference(model_name: str, sd, frames_np, size: int, batch: int, budget_
     return rep, want
 
 
-def measure_config(model_name: str, size: int, batch: int, half: bool, steps: int, warmup: int, cpu_budget_s: float = 0.0) -> dict:
+def measure_config(model_name: str, size: int, batch: int, half: bool, steps: int, warmup: int, cpu_budget_s: float = 0.0, fast_act: bool = False) -> dict:
     """One BASELINE configuration on this GPU: frames resident in HBM, rows returned to the host every step."""
     import torch
     from cvsd_amd import YOLO
     from cvsd_amd.weights import build_from_state_dict
     from tools import synth
     _, sd = synth.synthetic_checkpoint(model_name, seed=0)
-    model = YOLO(build_from_state_dict(model_name, sd), device=torch.cuda.current_device(), batch_chunk=batch, half=half)
+    model = YOLO(build_from_state_dict(model_name, sd), device=torch.cuda.current_device(), batch_chunk=batch, half=half, fast_act=fast_act)
     frames, frames_np = make_frames(batch, size, seed=2000 + batch)
     for _ in range(warmup):
         model._infer_rows(frames, 0.25, 0.7, None, 300, size)
@@ -296,18 +299,32 @@ def measure_config(model_name: str, size: int, batch: int, half: bool, steps: in
     achieved = conv_flops_per_frame(model_name, size) * batch / (conv_ms * 1e-3) / 1e12
     peak = F16_PEAK_TFLOPS if half else FP32_PEAK_TFLOPS
     plan = model.plan_info()
-    out = {"workload": f"{model_name} {size}x{size} batch {batch}" + (" half=True" if half else ""), "dtype": "f16" if half else "f32",
+    out = {"workload": f"{model_name} {size}x{size} batch {batch}" + (" half=True" if half else "") + (" fast_act=1 (tolerance mode, opt-in)" if fast_act else ""),
+           "dtype": "f16" if half else "f32",
            "value": round(batch * steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
            "roofline": {"achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                         **roofline_fractions(model_name, size, batch, half, conv_ms),
                         "launches_per_step": launches, "plan_hash": plan["plan_hash"], "plan_source": plan["plan_source"]},
            "activation_bytes": plan["activation_bytes"]}
+    if fast_act:
+        # parity of the tolerance mode, measured here (no CPU timing belongs to it): rows against the torch-CPU oracle and both against
+        # float64 on 4 of the benchmark's frames, and the head tensor against the CANONICAL engine's on the same frames
+        n_par = min(4, len(frames_np))
+        out["parity"] = parity_report(model, model_name, sd, frames_np[:n_par], size, f64_frames=2)
+        canon = YOLO(build_from_state_dict(model_name, sd), device=torch.cuda.current_device(), batch_chunk=n_par)
+        hf, hc = model.raw_head(frames_np[:n_par], imgsz=size), canon.raw_head(frames_np[:n_par], imgsz=size)
+        nc = model.nc
+        out["parity"]["vs_canonical_engine_head"] = {"box_abs_err_px": _delta_stats(np.abs(hf[:, :4] - hc[:, :4])),
+                                                     "score_abs_err": _delta_stats(np.abs(hf[:, 4:4 + nc] - hc[:, 4:4 + nc])),
+                                                     "identical_bits": bool(np.array_equal(hf, hc))}
+        del canon
     del frames, model
     torch.cuda.empty_cache()
     return out
 
 
-def config_cpu_and_parity(out: dict, model_name: str, size: int, batch: int, half: bool, steps: int, warmup: int, cpu_budget_s: float = 0.0) -> None:
+def config_cpu_and_parity(out: dict, model_name: str, size: int, batch: int, half: bool, steps: int, warmup: int, cpu_budget_s: float = 0.0,
+                          fast_act: bool = False) -> None:
     """Second phase, AFTER every GPU timing of the line: the torch-CPU reference at this config's batch and the parity figures of
     the same frames (the engine is re-created: its launch plans come from the plan file the first phase wrote).  Kept apart from
     the GPU timings because the CPU reference's worker threads keep spinning between calls and slow the host side of a
