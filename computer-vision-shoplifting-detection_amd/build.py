@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmi355yolo.so")
-SOURCES = ["conv_f32_k3s1.hip", "conv_f32_k3s2.hip", "conv_f32_k1.hip", "conv_f32_pipe.hip", "conv_f32_splitk.hip", "conv_f32_fused_s1.hip", "conv_f32_fused_s2.hip", "conv_f32_group.hip", "conv_igemm_f16.hip", "conv_f16_fused.hip", "conv_f16_small.hip", "conv_plan.hip",
+SOURCES = ["conv_f32_k3s1.hip", "conv_f32_k3s2.hip", "conv_f32_k1.hip", "conv_f32_pipe.hip", "conv_f32_splitk.hip", "conv_f32_fused_s1.hip", "conv_f32_fused_s2.hip", "conv_f32_group.hip", "conv_igemm_f16.hip", "conv_f16_fused.hip", "conv_f16_small.hip", "conv_f16_lw.hip", "conv_plan.hip",
            "misc_kernels.hip", "post_kernels.hip", "engine_load.hip", "engine_memory.hip", "engine_plans.hip", "engine_run.hip", "engine_abi.hip", "engine_ops.hip", "gmc_kernels.hip", "gmc_host.cpp", "tracker_host.cpp"]
 HEADERS = ["common.h", "detmath.h", "conv_f32.h", "conv_f32_inst.h", "conv_f16.h", "engine_internal.h", os.path.join("..", "..", "include", "mi355_yolo.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-result"]

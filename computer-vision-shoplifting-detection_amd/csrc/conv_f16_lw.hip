@@ -1,0 +1,227 @@
+// half=True path, second kernel family (round 4): 3x3 / stride-1 convs with the block's WEIGHTS in LDS ("lw"), a persistent block
+// loop and register-staged prefetch across chunk AND tile boundaries.  Replaces nothing in the reference by itself: it is another
+// launch plan (version 7) of the conv that conv_f16.h implements -- ultralytics' half=True predictor mode reached through
+// /root/reference/model.py:38, BASELINE config 5 (YOLOv8m 1280x1280 fp16) -- and produces the same bits as every other plan
+// (same k-block-major, tap-minor accumulation order on the same instruction).
+//
+// Why (profiles/r03_cfg5_*): in conv_igemm_f16 every wave streams its own weight fragments through the 64 B/clk vector
+// L1 inside the K loop (1 KiB per MFMA per PT pixel tiles), the halo tile of the next chunk is not requested before the current
+// chunk's MFMAs are done, and a block's prologue / epilogue are covered only by whatever other block happens to share the CU.
+// Here
+//   * a block = 4 waves = one 16 x 16 output tile x (CT * 16) couts; the wave owns 4 rows of the tile (PT = 4 pixel tiles) and
+//     ALL of the block's cout tiles, so the four waves read the same weight fragments -- staged ONCE per block and k-block into
+//     LDS (9 * CT KiB, fragment order: one ds_read_b128 per fragment, conflict-free) instead of four times through L1;
+//   * work = (tile, cout group, k-block) items walked by a persistent block; the global loads of item i + 1 (halo tile slice
+//     and weights, next tile's first k-block included) are in flight into registers while item i's MFMAs run from LDS;
+//   * the halo tile is [pixel][32 channels] with a 64-byte pixel stride and the 16-byte slot index XOR-swizzled by bit 2 of the
+//     pixel index: B-operand reads are conflict-free for ds_read_b128's lane groups without padding (20.7 KB instead of 31 KB,
+//     which is what lets CT = 6 run two blocks per CU);
+//   * two blocks per CU: one block's LDS write phase / epilogue under the other's MFMAs.
+#include "conv_f16.h"
+
+namespace mi355 {
+
+namespace {
+
+constexpr int kLwTile = 16, kLwHalo = 18, kLwPix = kLwHalo * kLwHalo;       // output tile edge, halo tile edge, halo pixels
+constexpr int kLwXBytes = kLwPix * 64;                                      // 32 channels x 2 bytes per halo pixel
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void conv3x3_lw_f16(ConvKArgs a) {
+    constexpr int PT = 4, NF = 9 * CT, NWU = (NF + 3) / 4, NXU = (kLwPix * 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kLwXBytes + NWU * 4096];       // weight region: whole passes of 4 fragments
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
+    const unsigned g = (unsigned)lane >> 4;
+
+    // What-if diagnostics, built only with -DMI355_F16_DIAG=1 (tools/ab_build.sh), selected by MI355_F16_EXP: 1 no global loads, 2 no LDS writes,
+    // 4 no stores, 8 weight fragments not re-read from LDS, 16 pixel fragments not re-read, 32 no barriers
+#ifdef MI355_F16_DIAG
+    const int exp_flags = a.lds_buf_floats;
+#else
+    constexpr int exp_flags = 0;
+#endif
+    const int gy = a.cgroups, n_units = a.n_tiles_total * gy, G = (int)gridDim.x;
+    const int my_units = ((int)blockIdx.x < n_units) ? (n_units - 1 - (int)blockIdx.x) / G + 1 : 0;
+    const int cib = a.cib, n_items = my_units * cib;
+    if (n_items == 0) return;
+
+    // unit j of this block -> (image, tile row, tile column, cout group): XCD-aware order (common.h), tile-major, cout group innermost
+    auto decode = [&](int j, int& b, int& ty, int& tx, int& cg) {
+        const unsigned u = blockIdx.x + (unsigned)j * (unsigned)G;
+        const unsigned n = (unsigned)n_units, qn = n >> 3, rn = n & 7, x = u & 7;
+        const unsigned logical = (x < rn ? x * (qn + 1) : rn * (qn + 1) + (x - rn) * qn) + (u >> 3);
+        const unsigned t = fastdiv(logical, FastDiv{a.fd_gy.ml, a.fd_gy.mh});
+        cg = (int)(logical - t * (unsigned)gy);
+        const unsigned tq = fastdiv(t, FastDiv{a.fd_tx.ml, a.fd_tx.mh});
+        tx = (int)(t - tq * (unsigned)a.tiles_x);
+        const unsigned bb = fastdiv(tq, FastDiv{a.fd_ty.ml, a.fd_ty.mh});
+        ty = (int)(tq - bb * (unsigned)a.tiles_y);
+        b = (int)bb;
+    };
+
+    // ---- load stream: item (jL, kL) = (unit, k-block) whose global loads are issued next --------------------------------------
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned q = (unsigned)tid & 3u;                                   // this thread's 16-byte slot (8 channels) of a halo pixel
+    const bool qok_last = (cib - 1) * 32 + 8 * (int)q < a.cin4;              // last k-block: channels beyond round_up(Cin, 8) read zeros
+    const int n_wfrag = a.n_ctiles * 9;
+    int jL = 0, kL = 0, wfr0 = 0;
+    unsigned voff[NXU];
+    __amdgpu_buffer_rsrc_t srs = wrsrc;
+    f16x8 px[NXU], pw[NWU];
+    // Every load is unconditional (a conditional load makes the compiler keep two homes for its destination and copy between them
+    // right behind the load, which waits for it): beyond the last item the stream re-reads the last one, weight fragments beyond
+    // 9 * CT read zeros through an offset past num_records.
+    auto prefetch = [&]() {
+        if (kL == 0) {
+            int b, ty, tx, cg;
+            decode(jL, b, ty, tx, cg);
+            srs = __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)a.src + (size_t)b * (size_t)a.img_src), 0, (int)((unsigned)a.img_src * 2u),
+                                                    0x00020000);
+            const int iy0 = ty * kLwTile - 1, ix0 = tx * kLwTile - 1;
+#pragma unroll
+            for (int u = 0; u < NXU; ++u) {
+                const int pix = u * 64 + (tid >> 2);
+                const int hy = (pix * 3641) >> 16, hx = pix - hy * kLwHalo;                      // pix / 18 for pix < 448
+                const int gyy = iy0 + hy, gxx = ix0 + hx;
+                const bool ok = pix < kLwPix && (unsigned)gyy < (unsigned)a.Hin && (unsigned)gxx < (unsigned)a.Win;
+                voff[u] = ok ? (unsigned)(__mul24(__mul24(gyy, a.Win) + gxx, a.src_cs) * 2) + q * 16u : kOOB;
+            }
+            wfr0 = cg * CT * 9;
+        }
+        const bool drop = (kL == cib - 1) && !qok_last;
+        if (!(exp_flags & 1)) {
+#pragma unroll
+        for (int u = 0; u < NXU; ++u)
+            px[u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(srs, (int)(drop ? kOOB : voff[u]), kL * 64, 0));
+#pragma unroll
+        for (int u = 0; u < NWU; ++u) {
+            const int f = 4 * u + wave;
+            const int fi = min(wfr0 + f, n_wfrag - 1);              // cout tiles beyond the last one re-read it (their results are never stored)
+            pw[u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(f < NF ? lane16 : kOOB), (fi * cib + kL) * 1024, 0));
+        }
+        }
+        if (jL + 1 < my_units || kL + 1 < cib) { if (++kL == cib) { kL = 0; ++jL; } }
+    };
+    // registers -> LDS.  Halo slot (pix, q) lives at pix * 64 + ((q ^ 2 * bit2(pix)) * 16); pix = u * 64 + tid / 4, so the swizzle bit
+    // is bit 4 of tid for every u.  Weight fragment f = 4 u + wave at f * 1024 + lane * 16 = u * 4096 + tid * 16.
+    const unsigned cx = (unsigned)(tid >> 2) * 64u + ((q ^ ((((unsigned)tid >> 4) & 1u) << 1)) * 16u);
+    auto commit = [&]() {
+        if (exp_flags & 2) return;
+#pragma unroll
+        for (int u = 0; u < NXU; ++u)
+            if (u * 64 + (tid >> 2) < kLwPix) *(f16x8*)(lds + cx + u * 4096) = px[u];
+#pragma unroll
+        for (int u = 0; u < NWU; ++u) *(f16x8*)(lds + kLwXBytes + u * 4096 + tid * 16) = pw[u];
+    };
+
+    // ---- compute stream ------------------------------------------------------------------------------------------------------
+    // B operand of pixel tile pt at tap (tr, tc): halo pixel (4 wave + pt + tr, (lane & 15) + tc), channel group g.  With r = pt + tr:
+    // byte = xbase + (r * 18 + tc) * 64 + 32 * swz(r, tc), xbase = (4 wave * 18 + (lane & 15)) * 64 + (g & 1) * 16 and
+    // swz(r, tc) = bit2(halo pixel index) ^ (g >> 1): 18 bits per lane, computed once.
+    const unsigned pl = (unsigned)(4 * wave * kLwHalo + (lane & 15));
+    const unsigned xbase = pl * 64u + (g & 1u) * 16u;
+    unsigned swm = 0;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) swm |= ((((pl + (unsigned)((i / 3) * kLwHalo + (i % 3))) >> 2) ^ (g >> 1)) & 1u) << i;
+    const unsigned wbase = (unsigned)kLwXBytes + lane16;
+    auto xfrag = [&](int r, int tc) -> f16x8 {
+        const unsigned off = xbase + (((swm >> (r * 3 + tc)) & 1u) << 5);
+        return *(const f16x8*)__builtin_assume_aligned(lds + off + (r * kLwHalo + tc) * 64, 16);
+    };
+    auto wfrag = [&](int m) -> f16x8 {                                  // micro-step m = tap * CT + ct
+        return *(const f16x8*)__builtin_assume_aligned(lds + wbase + ((m % CT) * 9 + m / CT) * 1024, 16);
+    };
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // One item = one k-block: 9 taps x CT cout tiles x 4 pixel tiles.  Micro-step (tap, ct) = 4 MFMAs on one weight fragment; weight
+    // fragments travel through a 3-slot ring two micro-steps ahead, pixel fragments are double-buffered per tap and fetched during
+    // the previous tap's micro-steps.
+    auto compute = [&]() {
+        f16x8 xf[2][PT], wr[3];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) xf[0][pt] = xfrag(pt, 0);
+        wr[0] = wfrag(0);
+        wr[1] = wfrag(1);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int m = t * CT + ct;
+                if (m + 2 < 9 * CT && !(exp_flags & 8)) wr[(m + 2) % 3] = wfrag(m + 2);
+                if (t + 1 < 9 && !(exp_flags & 16)) {
+#pragma unroll
+                    for (int pt = ct * PT / CT; pt < (ct + 1) * PT / CT; ++pt) xf[(t + 1) & 1][pt] = xfrag(pt + (t + 1) / 3, (t + 1) % 3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[m % 3], xf[t & 1][pt], acc[ct][pt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+    auto epilogue = [&](int j) {
+        int b, ty, tx, cg;
+        decode(j, b, ty, tx, cg);
+        const int ct0 = cg * CT;
+        const OutF16 o = make_out_f16(a.dst, a.dst_cs, a.img_dst, a.res, a.res_cs, a.img_res, b, a.Cout, a.act, a.out_f32);
+        int pixi[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int oy = ty * kLwTile + 4 * wave + pt, ox = tx * kLwTile + (lane & 15);
+            pixi[pt] = (oy < a.Hout && ox < a.Wout) ? __mul24(oy, a.Wout) + ox : -1;
+        }
+        f32x4 bias4[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+            bias4[ct] = *(const f32x4*)(a.bias + tile_cout0(ctile, lane >> 4, conv_f16_pairs(a.Cout)));
+        }
+        if (exp_flags & 4) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) pixi[pt] = acc[0][pt][0] == 12345.678f ? pixi[pt] : -1;
+        }
+        store_tiles_f16_v2<PT, CT>(o, acc, bias4, lane, ct0, pixi);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+
+    // Loop order: the iteration OPENS with the step that needs the previous iteration's global loads anyway (registers -> LDS), so the
+    // wait the compiler places at the loop header costs nothing; the loads of item i + 1 are then in flight during compute(i).  A
+    // finished unit's epilogue runs after the LDS writes and BEFORE the next loads are issued (vmcnt retires in order: waiting for those
+    // loads one iteration later must not mean waiting for younger stores), under the co-resident block's MFMAs.
+    prefetch();                                            // item 0
+    int jC = 0, kC = 0, jE = -1;
+    for (int i = 0;; ++i) {
+        if (i < n_items) commit();                         // item i
+        if (jE >= 0) { epilogue(jE); jE = -1; }
+        if (i == n_items) break;
+        prefetch();                                        // item i + 1
+        if (!(exp_flags & 32)) __syncthreads();
+        compute();
+        if (!(exp_flags & 32)) __syncthreads();            // every wave is done reading this item's LDS image
+        if (kC == cib - 1) jE = jC;
+        if (++kC == cib) { kC = 0; ++jC; }
+    }
+}
+
+typedef void (*KernelFn)(ConvKArgs);
+
+}  // namespace
+
+// version-7 launch plans: CT cout tiles per block (48 / 64 / 96 couts)
+const void* pick_conv_lw_f16(int CT) {
+    if (CT == 3) return (const void*)(KernelFn)&conv3x3_lw_f16<3>;
+    if (CT == 4) return (const void*)(KernelFn)&conv3x3_lw_f16<4>;
+    if (CT == 6) return (const void*)(KernelFn)&conv3x3_lw_f16<6>;
+    return nullptr;
+}
+
+}  // namespace mi355

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../computer-vision-shoplifting-detection_amd/csrc"
 OUT=${2:-exp}
 OBJ=/tmp/ab_obj_$OUT
 mkdir -p $OBJ
-SRCS="conv_f32_k3s1 conv_f32_k3s2 conv_f32_k1 conv_f32_pipe conv_f32_splitk conv_f32_fused_s1 conv_f32_fused_s2 conv_f32_group conv_igemm_f16 conv_f16_fused conv_f16_small conv_plan misc_kernels post_kernels engine_load engine_memory engine_plans engine_run engine_abi engine_ops gmc_kernels"
+SRCS="conv_f32_k3s1 conv_f32_k3s2 conv_f32_k1 conv_f32_pipe conv_f32_splitk conv_f32_fused_s1 conv_f32_fused_s2 conv_f32_group conv_igemm_f16 conv_f16_fused conv_f16_small conv_f16_lw conv_plan misc_kernels post_kernels engine_load engine_memory engine_plans engine_run engine_abi engine_ops gmc_kernels"
 pids=""
 for s in $SRCS; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 $1 -c $s.hip -o $OBJ/$s.o & pids="$pids $!"

@@ -16,9 +16,13 @@ desc = C.create_string_buffer(256)
 fl = 2.0 * n * (h // s) * (w // s) * cout * cin * k * k
 rows = []
 i = 0
+flt = os.environ.get("MB_FILTER")          # e.g. "v7": time only the plans whose description starts with it (one probe launch tells)
 while True:
-    _lib.check(fn(0, n, h, w, cin, cout, k, s, silu, res, i, 20, C.byref(ms), C.byref(npl), desc, 256))
-    rows.append((ms.value, desc.value.decode()))
+    if flt:
+        _lib.check(fn(0, n, h, w, cin, cout, k, s, silu, res, i, 1, C.byref(ms), C.byref(npl), desc, 256))
+    if not flt or desc.value.decode().startswith(flt):
+        _lib.check(fn(0, n, h, w, cin, cout, k, s, silu, res, i, 20, C.byref(ms), C.byref(npl), desc, 256))
+        rows.append((ms.value, desc.value.decode()))
     i += 1
     if i >= npl.value or (maxp and i >= maxp):
         break
@@ -26,8 +30,8 @@ print(f"conv {cin}->{cout} k{k} s{s} @{h}x{w} n={n} silu={silu} res={res}: {npl.
 srt = sorted(rows)
 for t, d in srt[:int(os.environ.get("MB_TOP", "10"))]:
     print(f"  {t*1e3:9.1f} us  {fl/t/1e9:7.1f} TFLOP/s   {d}")
-v2 = [r for r in srt if r[1].startswith("v2")][:6]
+v2 = [r for r in srt if r[1].startswith("v7")][:6]
 if v2:
-    print("  best v2 plans:")
+    print("  v7 plans (weights in LDS, persistent):")
 for t, d in v2:
     print(f"  {t*1e3:9.1f} us  {fl/t/1e9:7.1f} TFLOP/s   {d}")
