@@ -41,6 +41,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lw_f16(ConvKArgs a) {
 #else
     constexpr int exp_flags = 0;
 #endif
+    // A/B knobs (tools/ab_build.sh): MI355_LW_STAGGER = 64-cycle units the second co-resident block of a CU sleeps before its first item (the two
+    // blocks start in lockstep: same program, same durations); MI355_LW_OPAQUE_X = 1 keeps the 18 pixel-fragment addresses out of registers
+#ifndef MI355_LW_STAGGER
+#define MI355_LW_STAGGER 0
+#endif
+#ifndef MI355_LW_OPAQUE_X
+#define MI355_LW_OPAQUE_X (CT >= 6)
+#endif
+    if (MI355_LW_STAGGER > 0) {
+        const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);       // HW_ID.TG_ID: which of the CU's resident blocks this is
+        if (tg & 1u) __builtin_amdgcn_s_sleep(MI355_LW_STAGGER);
+    }
     const int gy = a.cgroups, n_units = a.n_tiles_total * gy, G = (int)gridDim.x;
     const int my_units = ((int)blockIdx.x < n_units) ? (n_units - 1 - (int)blockIdx.x) / G + 1 : 0;
     const int cib = a.cib, n_items = my_units * cib;
@@ -73,7 +85,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lw_f16(ConvKArgs a) {
     // Every load is unconditional (a conditional load makes the compiler keep two homes for its destination and copy between them
     // right behind the load, which waits for it): beyond the last item the stream re-reads the last one, weight fragments beyond
     // 9 * CT read zeros through an offset past num_records.
-    auto prefetch = [&]() {
+    // Split in two: the set-up of an item (scalar work, six offsets when a new unit begins) and its NXU + NWU loads, which compute()
+    // issues one at a time between its first micro-steps (MI355_LW_INTERLEAVE, default on): in the shadow of the MFMAs instead of as a
+    // phase of its own between the two barriers.
+    bool drop = false;
+    auto prefetch_setup = [&]() {
         if (kL == 0) {
             int b, ty, tx, cg;
             decode(jL, b, ty, tx, cg);
@@ -90,19 +106,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lw_f16(ConvKArgs a) {
             }
             wfr0 = cg * CT * 9;
         }
-        const bool drop = (kL == cib - 1) && !qok_last;
-        if (!(exp_flags & 1)) {
-#pragma unroll
-        for (int u = 0; u < NXU; ++u)
-            px[u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(srs, (int)(drop ? kOOB : voff[u]), kL * 64, 0));
-#pragma unroll
-        for (int u = 0; u < NWU; ++u) {
-            const int f = 4 * u + wave;
+        drop = (kL == cib - 1) && !qok_last;
+    };
+    auto prefetch_load = [&](int l) {                      // l: compile-time index, halo slots first
+        if (exp_flags & 1) return;
+        if (l < NXU) {
+            px[l] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(srs, (int)(drop ? kOOB : voff[l]), kL * 64, 0));
+        } else {
+            const int u = l - NXU, f = 4 * u + wave;
             const int fi = min(wfr0 + f, n_wfrag - 1);              // cout tiles beyond the last one re-read it (their results are never stored)
             pw[u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(f < NF ? lane16 : kOOB), (fi * cib + kL) * 1024, 0));
         }
-        }
+    };
+    auto prefetch_advance = [&]() {
         if (jL + 1 < my_units || kL + 1 < cib) { if (++kL == cib) { kL = 0; ++jL; } }
+    };
+    auto prefetch = [&]() {
+        prefetch_setup();
+#pragma unroll
+        for (int l = 0; l < NXU + NWU; ++l) prefetch_load(l);
+        prefetch_advance();
     };
     // registers -> LDS.  Halo slot (pix, q) lives at pix * 64 + ((q ^ 2 * bit2(pix)) * 16); pix = u * 64 + tid / 4, so the swizzle bit
     // is bit 4 of tid for every u.  Weight fragment f = 4 u + wave at f * 1024 + lane * 16 = u * 4096 + tid * 16.
@@ -127,7 +150,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lw_f16(ConvKArgs a) {
     for (int i = 0; i < 18; ++i) swm |= ((((pl + (unsigned)((i / 3) * kLwHalo + (i % 3))) >> 2) ^ (g >> 1)) & 1u) << i;
     const unsigned wbase = (unsigned)kLwXBytes + lane16;
     auto xfrag = [&](int r, int tc) -> f16x8 {
-        const unsigned off = xbase + (((swm >> (r * 3 + tc)) & 1u) << 5);
+        unsigned sw = swm;
+        if (MI355_LW_OPAQUE_X) asm volatile("" : "+v"(sw));             // recomputed per read (2 vector instructions) instead of 18 live addresses
+        const unsigned off = xbase + (((sw >> (r * 3 + tc)) & 1u) << 5);
         return *(const f16x8*)__builtin_assume_aligned(lds + off + (r * kLwHalo + tc) * 64, 16);
     };
     auto wfrag = [&](int m) -> f16x8 {                                  // micro-step m = tap * CT + ct
@@ -142,28 +167,44 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lw_f16(ConvKArgs a) {
     // One item = one k-block: 9 taps x CT cout tiles x 4 pixel tiles.  Micro-step (tap, ct) = 4 MFMAs on one weight fragment; weight
     // fragments travel through a 3-slot ring two micro-steps ahead, pixel fragments are double-buffered per tap and fetched during
     // the previous tap's micro-steps.
-    auto compute = [&]() {
-        f16x8 xf[2][PT], wr[3];
+#ifndef MI355_LW_INTERLEAVE
+#define MI355_LW_INTERLEAVE 1
+#endif
+#ifndef MI355_LW_WRING
+#define MI355_LW_WRING 3
+#endif
+#ifndef MI355_LW_PRIO
+#define MI355_LW_PRIO 0
+#endif
+    auto compute = [&](auto with_loads) {
+        constexpr bool WL = decltype(with_loads)::value;
+        constexpr int NL = NXU + NWU, M = 9 * CT;
+        constexpr int WR = MI355_LW_WRING, WA = WR - 1;          // weight-fragment ring: WR slots, WA micro-steps ahead
+        f16x8 xf[2][PT], wr[WR];
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) xf[0][pt] = xfrag(pt, 0);
-        wr[0] = wfrag(0);
-        wr[1] = wfrag(1);
+#pragma unroll
+        for (int m = 0; m < WA; ++m) wr[m] = wfrag(m);
+        if (MI355_LW_PRIO) __builtin_amdgcn_s_setprio(1);          // the MFMA phase outranks the co-resident block's staging instructions
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const int m = t * CT + ct;
-                if (m + 2 < 9 * CT && !(exp_flags & 8)) wr[(m + 2) % 3] = wfrag(m + 2);
+                if (m + WA < M && !(exp_flags & 8)) wr[(m + WA) % WR] = wfrag(m + WA);
                 if (t + 1 < 9 && !(exp_flags & 16)) {
 #pragma unroll
                     for (int pt = ct * PT / CT; pt < (ct + 1) * PT / CT; ++pt) xf[(t + 1) & 1][pt] = xfrag(pt + (t + 1) / 3, (t + 1) % 3);
                 }
+                if (WL && m < NL) prefetch_load(m);                 // next item's global loads: one per micro-step, all in the first half
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt)
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[m % 3], xf[t & 1][pt], acc[ct][pt], 0, 0, 0);
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[m % WR], xf[t & 1][pt], acc[ct][pt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        if (MI355_LW_PRIO) __builtin_amdgcn_s_setprio(0);
+        static_assert(NL <= M, "one load per micro-step");
     };
     auto epilogue = [&](int j) {
         int b, ty, tx, cg;
@@ -203,9 +244,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lw_f16(ConvKArgs a) {
         if (i < n_items) commit();                         // item i
         if (jE >= 0) { epilogue(jE); jE = -1; }
         if (i == n_items) break;
-        prefetch();                                        // item i + 1
-        if (!(exp_flags & 32)) __syncthreads();
-        compute();
+        if (MI355_LW_INTERLEAVE) {
+            prefetch_setup();                              // item i + 1: its loads are issued inside compute()
+            if (!(exp_flags & 32)) __syncthreads();
+            compute(std::true_type{});
+            prefetch_advance();
+        } else {
+            prefetch();
+            if (!(exp_flags & 32)) __syncthreads();
+            compute(std::false_type{});
+        }
         if (!(exp_flags & 32)) __syncthreads();            // every wave is done reading this item's LDS image
         if (kC == cib - 1) jE = jC;
         if (++kC == cib) { kC = 0; ++jC; }

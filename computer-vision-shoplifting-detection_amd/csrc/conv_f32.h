@@ -653,7 +653,10 @@ __global__ __launch_bounds__(256) void conv_splitk_f32(ConvKArgs a) {
 // 4g..4g+3 of pixel p: 64 contiguous bytes per pixel per 16-channel block), with a 4-deep register prefetch ring for
 // pixels (HBM latency) and weights (L2 latency).  No LDS, no barriers: waves drift apart and overlap each other's
 // epilogues.  Same canonical accumulation order as v1 (per 16-channel block a chain from +0; partials summed in block order).
-template <int PT, int CT, class KA = ConvKArgs>
+// UP (round 4): the nearest-2x upsample fused into the read side, as conv1x1_pipe_f32 has it -- the first a.up_c input channels (whole
+// 16-channel blocks) are read from the half-resolution tensor a.src2 at (y >> 1, x >> 1) instead of from a.src; same values in the same
+// order, so the same bits as the upsample kernel followed by the plain launch.  fd_tx / fd_ty divide by up_W / up_W * up_H.
+template <int PT, int CT, class KA = ConvKArgs, bool UP = false>
 __device__ __forceinline__ void conv1x1_stream_f32_body(const KA& a, const BlockId& bid) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63;
@@ -680,6 +683,20 @@ __device__ __forceinline__ void conv1x1_stream_f32_body(const KA& a, const Block
     for (int pt = 0; pt < PT; ++pt) {
         pl[pt] = (wave * PT + pt) * 16 + (lane & 15);
         xvo[pt] = (unsigned)(__mul24(pl[pt], a.src_cs) + 4 * g) * 4u;
+    }
+    unsigned xvo2[UP ? PT : 1];                                      // UP: byte offset of the pixel's half-resolution source inside a.src2
+    __amdgpu_buffer_rsrc_t x2rs = xrs;
+    const int up_blocks = UP ? a.up_c >> 4 : 0;
+    if constexpr (UP) {
+        const int W2 = a.up_W >> 1, H2 = a.up_H >> 1;
+        x2rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src2, 0, (int)((unsigned)(total >> 2) * (unsigned)a.src2_cs * 4u), 0x00020000);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const unsigned p = (unsigned)min(p0 + pl[pt], total - 1);
+            const unsigned b = fastdiv(p, FastDiv{a.fd_ty.ml, a.fd_ty.mh}), r = p - b * (unsigned)(a.up_W * a.up_H);
+            const unsigned y = fastdiv(r, FastDiv{a.fd_tx.ml, a.fd_tx.mh}), x = r - y * (unsigned)a.up_W;
+            xvo2[pt] = (((b * (unsigned)H2 + (y >> 1)) * (unsigned)W2 + (x >> 1)) * (unsigned)a.src2_cs + 4u * (unsigned)g) * 4u;
+        }
     }
     int wbase[CT];                                                   // floats from a.wpk
 #pragma unroll
@@ -710,9 +727,15 @@ __device__ __forceinline__ void conv1x1_stream_f32_body(const KA& a, const Block
         for (int ct = 0; ct < CT; ++ct)
             w[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)lane16, (wbase[ct] + l_it * 256) * 4, 0));
         const bool oob = tail_oob && (l_it == n_it - 1);
+        if (UP && l_it < up_blocks) {                                // wave-uniform: this 16-channel block lives in the half-resolution tensor
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt)
-            x[pt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(oob ? 0x80000000u : xvo[pt]), l_it * 64, 0));
+            for (int pt = 0; pt < PT; ++pt)
+                x[pt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x2rs, (int)xvo2[UP ? pt : 0], l_it * 64, 0));
+        } else {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+                x[pt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(oob ? 0x80000000u : xvo[pt]), l_it * 64, 0));
+        }
         if (l_it + 1 < n_it) ++l_it;                                 // clamp instead of guarding the loads
     };
     auto mma = [&](const f32x4* w, const f32x4* x) {              // one 16-channel block: chain from +0, partial added to the sum
@@ -768,6 +791,10 @@ __device__ __forceinline__ void conv1x1_stream_f32_body(const KA& a, const Block
 template <int PT, int CT>
 __global__ __launch_bounds__(256, (PT * CT >= 16 ? 2 : PT * CT >= 8 ? 3 : 1)) void conv1x1_stream_f32(ConvKArgs a) {
     conv1x1_stream_f32_body<PT, CT>(a, MI355_BLOCK_ID());
+}
+template <int PT, int CT>
+__global__ __launch_bounds__(256, (PT * CT >= 16 ? 2 : PT * CT >= 8 ? 3 : 1)) void conv1x1_stream_up_f32(ConvKArgs a) {
+    conv1x1_stream_f32_body<PT, CT, ConvKArgs, true>(a, MI355_BLOCK_ID());
 }
 
 // ---------------------------------------------------------------------------------------------- v4 (1x1 only)

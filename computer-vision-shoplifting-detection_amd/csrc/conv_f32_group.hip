@@ -95,7 +95,7 @@ int group_kind(const ConvLaunch& l, int ks, int stride) {
         return G_IGEMM + ((stride - 1) * 2 + (f2 ? 1 : 0)) * 12 + (l.PT - 1) * 6 + (l.CT - 1) * 3 + lg(l.WP);
     if (l.version == 6 && ks == 3 && (l.PT == 1 || l.PT == 2) && (l.CT == 1 || l.CT == 2) && (stride == 1 || stride == 2))
         return G_SPLITK + (stride - 1) * 4 + (l.PT - 1) * 2 + (l.CT - 1);
-    if (l.version == 3 && ks == 1 && lg(l.PT) >= 0 && lg(l.CT) >= 0 && l.PT * l.CT <= 4)
+    if (l.version == 3 && ks == 1 && !l.a.up_c && lg(l.PT) >= 0 && lg(l.CT) >= 0 && l.PT * l.CT <= 4)
         return G_STREAM + lg(l.PT) * 3 + lg(l.CT);
     return -1;
 }

@@ -14,6 +14,7 @@ KernelFn pick_f32_k3s2(int CT, int WP, int PT);       // conv_f32_k3s2.hip
 KernelFn pick_f32_k1(int CT, int WP, int PT);         // conv_f32_k1.hip
 // conv1x1_stream_f32<PT, CT>: CT in {1, 2, 4}, PT in {1, 2, 4}
 KernelFn pick_f32_stream(int CT, int PT);     // conv_f32_k1.hip
+KernelFn pick_f32_stream_up(int CT, int PT);  // conv_f32_k1.hip: upsample fused into the read side
 // conv1x1_pipe_f32<PT, CT, WP, SINGLE, NKK>: PT 0 / 4 = 4 pixel tiles per wave (NKK = 8 when ck > 64, then CT <= 2), PT 1 / 2 =
 // small pixel tiles for latency-bound launches (ck <= 64); CT in {1, 2, 4}, WP in {1, 2, 4}
 KernelFn pick_f32_pipe(int CT, int WP, bool single, int ck, int PT);   // conv_f32_pipe.hip

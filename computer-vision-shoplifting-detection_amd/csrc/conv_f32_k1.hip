@@ -35,5 +35,18 @@ KernelFn pick_f32_stream(int CT, int PT) {
     if (CT == 4 && PT == 4) return &conv1x1_stream_f32<4, 4>;
     return nullptr;
 }
+// the same with the nearest-2x upsample fused into the read side (latency-bound launches: the only other kernel with the fused read is the pipelined one)
+KernelFn pick_f32_stream_up(int CT, int PT) {
+    if (CT == 1 && PT == 1) return &conv1x1_stream_up_f32<1, 1>;
+    if (CT == 2 && PT == 1) return &conv1x1_stream_up_f32<1, 2>;
+    if (CT == 4 && PT == 1) return &conv1x1_stream_up_f32<1, 4>;
+    if (CT == 1 && PT == 2) return &conv1x1_stream_up_f32<2, 1>;
+    if (CT == 1 && PT == 4) return &conv1x1_stream_up_f32<4, 1>;
+    if (CT == 2 && PT == 2) return &conv1x1_stream_up_f32<2, 2>;
+    if (CT == 2 && PT == 4) return &conv1x1_stream_up_f32<4, 2>;
+    if (CT == 4 && PT == 2) return &conv1x1_stream_up_f32<2, 4>;
+    if (CT == 4 && PT == 4) return &conv1x1_stream_up_f32<4, 4>;
+    return nullptr;
+}
 
 }  // namespace mi355

@@ -298,7 +298,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
                           : p.f2 ? (KernelFn)pick_conv_fused_f16(c.stride, p.CT, p.WP, p.PT)
                                  : (p.version == 1 && (p.PT == 1 || p.PT == 2)) ? (KernelFn)pick_conv_small_f16(c.k, c.stride, p.CT, p.WP, p.PT)
                                  : (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.version == 3 ? p.buf_floats : p.PT))
-                       : (p.version == 3 ? pick_f32_stream(p.CT, p.buf_floats)
+                       : (p.version == 3 ? (c.src2 ? pick_f32_stream_up(p.CT, p.buf_floats) : pick_f32_stream(p.CT, p.buf_floats))
                           : p.version == 4 ? pick_f32_pipe(p.CT, p.WP, c.Cin <= p.ck, p.ck, p.PT)
                           : p.version == 6 ? pick_f32_splitk(c.stride, p.CT, p.PT)
                           : p.f2 ? (c.stride == 1 ? pick_f32_fused_s1(p.CT, p.WP, p.PT) : pick_f32_fused_s2(p.CT, p.WP, p.PT))
@@ -401,6 +401,10 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
         out->grid_y = (unsigned)((a.n_ctiles + p.CT - 1) / p.CT);
         out->lds = 0;
         out->a.tiles_x = (int)out->grid_x;
+        if (c.src2) {            // upsample fused into the read side: per-lane (image, row, column) of a flattened pixel by scalar-made magic numbers
+            if ((c.up_c & 15) || (long long)(a.Wout / 4) * c.src2_cs * 4 >= (1ll << 31)) return "conv: streaming kernel cannot fuse this upsample";
+            out->a.fd_tx = make_fastdiv((unsigned)c.Win); out->a.fd_ty = make_fastdiv((unsigned)(c.Win * c.Hin));
+        }
     }
     out->flops = 2.0 * c.B * c.Hout * c.Wout * ((double)c.Cout * c.Cin * c.k * c.k + (p.f2 ? (double)c.f2_cout * (c.Cout + c.f2_lead_c) : 0.0));
     return nullptr;
@@ -426,7 +430,7 @@ const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out
     if (plans.empty()) return "conv: no launch plan fits in LDS";
     const char* last_err = nullptr;
     for (const Plan& p : plans) {
-        if (c.src2 && p.version != 4) continue;       // upsample-on-read exists in the v4 kernels only
+        if (c.src2 && p.version != 4 && !(p.version == 3 && !half)) continue;       // upsample-on-read: the pipelined kernels and the fp32 streaming kernel
         ConvLaunch l{};
         if (const char* e = build_launch(c, p, &l)) {   // e.g. the fused form exists for fewer wave shapes than the plain one
             last_err = e;

@@ -1,4 +1,5 @@
 // Single-operator entry points of include/mi355_yolo.h (host pointers in and out; the parity tests isolate a kernel with them).
+#include <limits>
 #include "engine_internal.h"
 
 using namespace mi355;
@@ -106,6 +107,48 @@ int mi355_op_conv2d_f16(int device_id, const float* x, int n, int h, int w, int 
                         int* n_plans) {
     return op_conv2d_impl(device_id, x, n, h, w, cin, w_oihw, bias, cout, k, stride, silu, residual, y, plan_index, n_plans, true,
                           out_f32 != 0);
+}
+
+// Pointwise conv over cat(upsample2x(x_half), x_skip) with the upsample fused into the conv's read side (fp32): the parity hook of the
+// neck's Upsample -> Concat -> C2f.cv1 chain as the engine runs it (the up channels of the concat buffer are never written: they
+// are poisoned here, so a plan that reads them shows).
+int mi355_op_conv1x1_upcat(int device_id, const float* x_half, const float* x_skip, int n, int h, int w, int up_c, int skip_c,
+                           const float* w_oihw, const float* bias, int cout, int silu, float* y, int plan_index, int* n_plans) {
+    if (!x_half || !x_skip || !w_oihw || !bias || !y || n <= 0 || h <= 0 || w <= 0 || up_c <= 0 || skip_c <= 0 || cout <= 0) return fail(MI355_EINVAL, "bad argument");
+    if ((h & 1) || (w & 1) || (up_c & 15)) return fail(MI355_EINVAL, "h and w must be even and up_c a multiple of 16");
+    HIPCHK(hipSetDevice(device_id));
+    const int cin = up_c + skip_c, cs_in = round_up(cin, 4), cs_h = round_up(up_c, 4), cs_out = round_up(cout, 4);
+    const size_t np = (size_t)n * h * w, nph = np / 4;
+    std::vector<float> xin(np * cs_in, 0.f), xh(nph * cs_h, 0.f), yout(np * cs_out, 0.f);
+    const float poison = std::numeric_limits<float>::quiet_NaN();
+    for (size_t p = 0; p < np; ++p) {
+        for (int c = 0; c < up_c; ++c) xin[p * cs_in + c] = poison;
+        std::memcpy(&xin[p * cs_in + up_c], x_skip + p * skip_c, (size_t)skip_c * 4);
+    }
+    for (size_t p = 0; p < nph; ++p) std::memcpy(&xh[p * cs_h], x_half + p * up_c, (size_t)up_c * 4);
+    DevMem dm; float *d_x, *d_h, *d_y, *d_w, *d_b, *d_z;
+    HIPCHK(dm.alloc(&d_z, 256)); HIPCHK(hipMemset(d_z, 0, 256));
+    HIPCHK(dm.alloc(&d_x, xin.size() * 4)); HIPCHK(hipMemcpy(d_x, xin.data(), xin.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(dm.alloc(&d_h, xh.size() * 4)); HIPCHK(hipMemcpy(d_h, xh.data(), xh.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(dm.alloc(&d_y, yout.size() * 4)); HIPCHK(hipMemset(d_y, 0, yout.size() * 4));
+    std::vector<float> pk(packed_weight_floats(cout, cin, 1)), bp(round_up(cout, 16), 0.f);
+    pack_conv_weights(w_oihw, cout, cin, 1, pk.data());
+    std::memcpy(bp.data(), bias, (size_t)cout * 4);
+    HIPCHK(dm.alloc(&d_w, pk.size() * 4)); HIPCHK(hipMemcpy(d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(dm.alloc(&d_b, bp.size() * 4)); HIPCHK(hipMemcpy(d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+    ConvArgs a{};
+    a.src = d_x; a.src_cs = cs_in; a.dst = d_y; a.dst_cs = cs_out; a.wpk = d_w; a.bias = d_b; a.zeros = d_z;
+    a.src2 = d_h; a.src2_cs = cs_h; a.up_c = up_c;
+    a.B = n; a.Hin = h; a.Win = w; a.Hout = h; a.Wout = w; a.Cin = cin; a.Cout = cout; a.k = 1; a.stride = 1; a.pad = 0; a.act = silu ? 1 : 0;
+    std::vector<ConvLaunch> cands;
+    KCHK(plan_conv_candidates(a, &cands));
+    const ConvLaunch& l = cands[(size_t)(plan_index < 0 ? 0 : plan_index) % cands.size()];
+    if (n_plans) *n_plans = (int)cands.size();
+    KCHK(run_conv(l, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(yout.data(), d_y, yout.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < np; ++p) std::memcpy(y + p * cout, &yout[p * cs_out], (size_t)cout * 4);
+    return MI355_OK;
 }
 
 // Conv3x3 (+bias+SiLU) -> Conv1x1 (+bias, optional SiLU) as ONE fused launch (conv_igemm_f32 / _f16 <..., F2 = true>): the parity

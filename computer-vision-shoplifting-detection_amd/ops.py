@@ -47,6 +47,22 @@ def conv2d(x_nhwc: np.ndarray, w_oihw: np.ndarray, bias: np.ndarray, stride: int
     return (y, npl.value) if return_n_plans else y
 
 
+def conv1x1_upcat(x_half: np.ndarray, x_skip: np.ndarray, w_oihw: np.ndarray, bias: np.ndarray, silu: bool = True, device: int = 0,
+                  plan: int = 0, return_n_plans: bool = False):
+    """Pointwise conv over cat(upsample2x(x_half), x_skip) with the upsample fused into the read side (fp32):
+    x_half [N,H/2,W/2,Cu], x_skip [N,H,W,Cs], w [Cout,Cu+Cs,1,1] -> [N,H,W,Cout]."""
+    xh, xs, w, b = _f32(x_half), _f32(x_skip), _f32(w_oihw), _f32(bias)
+    n, h, wd, cs = xs.shape
+    cu, cout = xh.shape[3], w.shape[0]
+    if xh.shape != (n, h // 2, wd // 2, cu) or w.shape != (cout, cu + cs, 1, 1) or b.shape != (cout,):
+        raise ValueError("shape mismatch")
+    y = np.empty((n, h, wd, cout), dtype=np.float32)
+    npl = C.c_int(0)
+    _lib.check(_lib.lib().mi355_op_conv1x1_upcat(device, xh.ctypes.data, xs.ctypes.data, n, h, wd, cu, cs, w.ctypes.data, b.ctypes.data,
+                                                 cout, int(silu), y.ctypes.data, int(plan), C.byref(npl)))
+    return (y, npl.value) if return_n_plans else y
+
+
 def conv2d_fused(x_nhwc: np.ndarray, w1: np.ndarray, b1: np.ndarray, w2: np.ndarray, b2: np.ndarray, stride: int = 1, silu2: bool = False,
                  device: int = 0, plan: int = 0, return_n_plans: bool = False, half: bool = False, out_f32: bool = False):
     """Conv3x3 + bias + SiLU -> Conv1x1 + bias (+SiLU) as one fused launch: x [N,H,W,Cin] -> [N,H/s,W/s,C2].

@@ -195,6 +195,13 @@ int  mi355_op_conv2d(int device_id, const float* x, int n, int h, int w, int cin
 int  mi355_op_conv2d_f16(int device_id, const float* x, int n, int h, int w, int cin, const float* w_oihw,
                          const float* bias, int cout, int k, int stride, int silu, const float* residual, float* y,
                          int out_f32, int plan_index, int* n_plans);
+/* Pointwise conv over the channel concatenation of a nearest-2x upsampled half-resolution tensor and a full-resolution one, with the
+ * upsample fused into the conv's read side, as the engine runs the neck's Upsample -> Concat -> C2f.cv1 (fp32; ultralytics
+ * nn/modules: nn.Upsample(None, 2, "nearest"), Concat, C2f.cv1): x_half[n][h/2][w/2][up_c] (up_c a multiple of 16),
+ * x_skip[n][h][w][skip_c], w[cout][up_c + skip_c][1][1] -> y[n][h][w][cout].  Must equal mi355_op_conv2d on the materialised
+ * concatenation, bit for bit, for every plan_index. */
+int  mi355_op_conv1x1_upcat(int device_id, const float* x_half, const float* x_skip, int n, int h, int w, int up_c, int skip_c,
+                            const float* w_oihw, const float* bias, int cout, int silu, float* y, int plan_index, int* n_plans);
 /* Conv3x3 (stride 1|2, pad 1) + bias + SiLU -> Conv1x1 + bias (+SiLU if silu2) run as ONE fused launch, the way the engine runs
  * a 3x3 conv whose only reader is a pointwise conv (the first conv's output never leaves the chip).  x[n][h][w][cin],
  * w1[c1][cin][3][3], b1[c1], w2[c2][c1][1][1], b2[c2] -> y[n][h/stride][w/stride][c2]; must equal the two convs run separately,

@@ -92,6 +92,29 @@ def test_every_launch_plan_gives_the_same_bits(n, h, w, cin, cout, k, stride):
                                       err_msg=f"plan {plan} of {n_plans}")
 
 
+@pytest.mark.parametrize("n,h,w,cu,cs,cout", [(1, 40, 40, 256, 128, 128), (1, 80, 80, 128, 64, 64), (2, 20, 24, 32, 16, 48), (3, 12, 10, 48, 51, 80),
+                                              (16, 40, 40, 256, 128, 128)])
+def test_pointwise_conv_reading_through_the_upsample_every_plan(n, h, w, cu, cs, cout):
+    """The neck's Upsample -> Concat -> C2f.cv1 (ultralytics yolov8.yaml head, layers 10-12 / 13-15) as the engine runs it: the conv reads
+    the up channels from the half-resolution map at (y >> 1, x >> 1); the concat buffer's up channels are never written (the op entry
+    poisons them with NaN).  Every plan -- the pipelined kernels and, round 4, the LDS-free streaming kernel that latency-bound passes
+    use -- against the canonical-order oracle on the materialised concatenation, bit for bit."""
+    from cvsd_amd import ops
+    from oracle import det
+    rng = np.random.default_rng(cu + cs + cout + h)
+    xh = rng.standard_normal((n, h // 2, w // 2, cu), dtype=np.float32)
+    xs = rng.standard_normal((n, h, w, cs), dtype=np.float32)
+    wt = (rng.standard_normal((cout, cu + cs, 1, 1)) / np.sqrt(cu + cs)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    cat = np.concatenate([xh.repeat(2, axis=1).repeat(2, axis=2), xs], axis=3)
+    ref = det.conv2d(cat, wt, b, stride=1, act=True, residual=None)
+    y, n_plans = ops.conv1x1_upcat(xh, xs, wt, b, silu=True, return_n_plans=True)
+    np.testing.assert_array_equal(y, ref)
+    assert n_plans >= 2
+    for plan in range(1, n_plans):
+        np.testing.assert_array_equal(ops.conv1x1_upcat(xh, xs, wt, b, silu=True, plan=plan), ref, err_msg=f"plan {plan} of {n_plans}")
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout", [(1, 80, 80, 64, 80), (1, 160, 160, 64, 64), (2, 40, 40, 128, 80)])
 def test_head_final_conv_without_activation_every_plan_repeated(n, h, w, cin, cout):
     """Regression (round 3, common.h:buffer_store_b128): a head's final conv -- pointwise, NO activation -- computes the next tile's
