@@ -568,7 +568,7 @@ def main() -> None:
                    "parallelism": f"frame-sharded dp{world}", "collectives_backend": backend, "ranks": world,
                    "collective_world_size": comm_world,
                    "collectives_per_step": 0 if world == 1 else 2},
-        "roofline": {"bound": "mfma", "kernel": ("conv_igemm_f16 + conv1x1_pipe_f16" if args.half else "conv_igemm_f32 + conv1x1_pipe_f32 + conv1x1_stream_f32") + " (every conv launch of a step)",
+        "roofline": {"bound": "mfma", "kernel": ("conv_igemm_f16 + conv3x3_lw_f16 + conv1x1_pipe_f16" if args.half else "conv_igemm_f32 + conv1x1_pipe_f32 + conv1x1_stream_f32") + " (every conv launch of a step)",
                      "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
                      **{k: v for k, v in roofline_fractions(args.model, args.size, B, args.half, conv_ms).items() if k != "bound"},

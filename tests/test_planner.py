@@ -45,3 +45,17 @@ def test_fused_pointwise_stage_checks_its_own_destination_stride():
     assert ops.plan_versions(1, H, W, 16, 16, 3, f2_cout=32, f2_dst_cs=cs2 // 2)
     with pytest.raises(ValueError):
         ops.plan_versions(1, H, W, 16, 16, 3, f2_cout=32, f2_dst_cs=cs2)
+
+
+def test_half_3x3_stride_1_convs_are_offered_the_lds_weights_kernels_and_nothing_else_is():
+    """Round 4: launch-plan version 7 (csrc/conv_f16_lw.hip: block weights staged in LDS, persistent blocks, 16 x 16 output tile x 48 / 64 / 96
+    couts) exists for half=True 3x3 / stride-1 convs without a fused pointwise stage; every other conv keeps its earlier candidate list."""
+    v = ops.plan_versions(16, 80, 80, 192, 192, 3, half=True, src_cs=192, dst_cs=192)
+    assert 7 in v and 1 in v
+    assert v.count(7) == 3                                                                     # CT 6, 4 and 3 all tile 12 cout tiles
+    assert 7 not in ops.plan_versions(16, 80, 80, 192, 192, 3)                                 # fp32
+    assert 7 not in ops.plan_versions(16, 80, 80, 192, 192, 3, stride=2, half=True, src_cs=192, dst_cs=192)
+    assert 7 not in ops.plan_versions(16, 80, 80, 192, 192, 1, half=True, src_cs=192, dst_cs=192)
+    assert set(ops.plan_versions(16, 80, 80, 64, 64, 3, f2_cout=64, half=True, src_cs=64, dst_cs=64, f2_dst_cs=64)) == {101}
+    assert 7 not in ops.plan_versions(16, 80, 80, 16, 16, 3, half=True, src_cs=16, dst_cs=16)  # one cout tile: the smallest block covers three
+    assert 7 not in ops.plan_versions(16, 4, 4, 192, 192, 3, half=True, src_cs=192, dst_cs=192)    # maps smaller than half a tile

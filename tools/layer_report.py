@@ -135,7 +135,7 @@ for p in passes:
     for r in p:
         kn = r["Kernel_Name"]; kn = kn[:kn.find("(")] if "(" in kn else kn
         agg[kn][0] += 1; agg[kn][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-is_conv = lambda k: "conv_igemm" in k or "conv1x1_" in k or "conv_splitk" in k
+is_conv = lambda k: "conv_igemm" in k or "conv1x1_" in k or "conv_splitk" in k or "conv3x3_lw" in k
 conv_calls = sum(v[0] for k, v in agg.items() if is_conv(k)); conv_us = sum(v[1] for k, v in agg.items() if is_conv(k))
 all_us = sum(v[1] for v in agg.values())
 print(f"\nkernel summary over {len(passes)} real passes:")

@@ -27,7 +27,7 @@ _fetch_line = json.loads([l for l in open(os.path.join(ROOT, "gpurun_out", f"{ta
 n_conv = _fetch_line["roofline"]["launches_per_step"]
 plan_hashes = {k: json.loads([l for l in open(os.path.join(ROOT, "gpurun_out", f"{tag}_{k}.log")) if l.startswith('{"metric')][-1])["roofline"].get("plan_hash")
                for k in ("trace", "fetch", "write") if os.path.exists(os.path.join(ROOT, "gpurun_out", f"{tag}_{k}.log"))}
-is_conv = lambda name: "conv_igemm" in name or "conv1x1_" in name or "conv_splitk" in name or "conv_group" in name
+is_conv = lambda name: "conv_igemm" in name or "conv1x1_" in name or "conv_splitk" in name or "conv_group" in name or "conv3x3_lw" in name
 
 
 def conv_sum(pat, counter, passes=6):
