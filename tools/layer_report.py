@@ -65,7 +65,7 @@ if steps:
         d = [(int(p[0][j]["End_Timestamp"]) - int(p[0][j]["Start_Timestamp"])) / 1e3 for p in passes]
         us = statistics.median(d); tot += us
         r = passes[0][0][j]
-        kn = r["Kernel_Name"]; kn = kn[:kn.find("(")] if "(" in kn else kn
+        kn = r["Kernel_Name"].replace("(anonymous namespace)::", ""); kn = kn[:kn.find("(")] if "(" in kn else kn
         kn = kn.replace("void mi355::", "").replace("mi355::", "")
         fl = sum(2.0 * c.cout * c.cin * c.k * c.k * (size // c.stride_div) ** 2 * chunk for c in (prog.convs[prog.ops[o].conv] for o in ops_l if prog.ops[o].type in (OP_CONV, OP_STEM)))
         label = " | ".join(prog.convs[prog.ops[o].conv].name if prog.ops[o].type in (OP_CONV, OP_STEM) else kind[prog.ops[o].type] for o in ops_l) or frag
@@ -133,7 +133,7 @@ import collections
 agg = collections.defaultdict(lambda: [0, 0.0])
 for p in passes:
     for r in p:
-        kn = r["Kernel_Name"]; kn = kn[:kn.find("(")] if "(" in kn else kn
+        kn = r["Kernel_Name"].replace("(anonymous namespace)::", ""); kn = kn[:kn.find("(")] if "(" in kn else kn
         agg[kn][0] += 1; agg[kn][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 is_conv = lambda k: "conv_igemm" in k or "conv1x1_" in k or "conv_splitk" in k or "conv3x3_lw" in k
 conv_calls = sum(v[0] for k, v in agg.items() if is_conv(k)); conv_us = sum(v[1] for k, v in agg.items() if is_conv(k))
@@ -143,5 +143,5 @@ print(f"{'kernel':60s} {'calls':>6s} {'total_us':>11s} {'avg_us':>9s} {'%':>6s}"
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"{k[:60]:60s} {v[0]:6d} {v[1]:11.1f} {v[1] / v[0]:9.1f} {100 * v[1] / all_us:6.2f}")
 conv_flops = sum(2.0 * c.cout * c.cin * c.k * c.k * (size // c.stride_div) ** 2 * chunk for c in prog.convs if c.cin != 3)
-print(f"conv kernels (conv_igemm_* + conv1x1_stream_* + conv1x1_pipe_*, all instances): {conv_calls} launches, avg {conv_us / conv_calls:.1f} us, {conv_us / len(passes):.1f} us per pass "
+print(f"conv kernels (conv_igemm_* + conv3x3_lw_* + conv1x1_stream_* + conv1x1_pipe_*, all instances): {conv_calls} launches, avg {conv_us / conv_calls:.1f} us, {conv_us / len(passes):.1f} us per pass "
       f"-> {conv_flops / (conv_us / len(passes)) / 1e6:.2f} TFLOP/s")
