@@ -106,6 +106,7 @@ SIGNATURES = {
     "mi355_gmc_step_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]),
     "mi355_gmc_step_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_gmc_pending_frame": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), _i32p, _i32p]),
     "mi355_tracker_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "mi355_tracker_destroy": (None, [C.c_void_p]),
     "mi355_tracker_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -558,6 +559,7 @@ struct mi355_gmc {
     int tab_key[4] = {0, 0, 0, 0};                             // (height, width, oh, ow) the resize tables on the device belong to
     float* d_pts = nullptr; float* d_next = nullptr; uint8_t* d_status = nullptr; int pts_cap = 0;
     uint8_t* h_pin = nullptr; size_t pin_cap = 0;
+    hipEvent_t ev_up = nullptr; int up_h = 0, up_w = 0;        // recorded behind the pending step's frame upload (mi355_gmc_pending_frame)
     // the pending step
     bool pending = false; int oh = 0, ow = 0, n_lk = 0;
     size_t o_hgray = 0, o_heig = 0, o_hok = 0, o_hnext = 0, o_hstatus = 0;
@@ -571,6 +573,10 @@ struct mi355_gmc {
     int prev_h = 0, prev_w = 0; bool have_prev_pts = false;
     bool track_pending = false; int t_oh = 0, t_ow = 0, t_n = 0;
     std::vector<uint8_t> host_frame; int hf_h = 0, hf_w = 0;   // host object: the frame of the pending step
+    // collect worker (device objects): the host half of a step -- wait for the stream, order the new corners, RANSAC -- runs on a thread of
+    // its own from the moment track_begin has enqueued the step, i.e. beside the detector pass the caller runs next; track_finish joins it
+    std::thread worker; std::mutex mu; std::condition_variable cv;
+    bool job_ready = false, job_done = false, worker_stop = false; int job_rc = 0; double job_H[6] = {1, 0, 0, 0, 1, 0};
     // mi355_gmc_track_batch: device buffers of one batch (grow-only) and their pinned mirror
     uint8_t* d_batch = nullptr; size_t batch_cap = 0;
     uint8_t* h_batch = nullptr; size_t hbatch_cap = 0;
@@ -601,10 +607,16 @@ extern "C" int mi355_gmc_create(int device, mi355_gmc** out) {
 }
 
 extern "C" void mi355_gmc_destroy(mi355_gmc* g) {
+    if (g && g->worker.joinable()) {
+        { std::lock_guard<std::mutex> lk(g->mu); g->worker_stop = true; }
+        g->cv.notify_all();
+        g->worker.join();
+    }
     if (!g) return;
     if (g->host) { delete g; return; }
     (void)hipSetDevice(g->device);
     if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
+    if (g->ev_up) (void)hipEventDestroy(g->ev_up);
     if (g->d_front) (void)hipFree(g->d_front);
     for (int i = 0; i < 2; ++i) if (g->d_pyr[i]) (void)hipFree(g->d_pyr[i]);
     if (g->d_pts) (void)hipFree(g->d_pts); if (g->d_next) (void)hipFree(g->d_next); if (g->d_status) (void)hipFree(g->d_status);
@@ -674,6 +686,8 @@ extern "C" int mi355_gmc_step_begin(mi355_gmc* g, const uint8_t* bgr, int height
     uint8_t* hp = g->h_pin;
     std::memcpy(hp, bgr, nb);
     GCHK(hipMemcpyAsync(g->d_front, hp, nb, hipMemcpyHostToDevice, g->stream));
+    if (!g->ev_up) GCHK(hipEventCreateWithFlags(&g->ev_up, hipEventDisableTiming));
+    GCHK(hipEventRecord(g->ev_up, g->stream)); g->up_h = height; g->up_w = width;
     if (resize && !(g->tab_key[0] == height && g->tab_key[1] == width && g->tab_key[2] == oh && g->tab_key[3] == ow)) {
         std::memcpy(hp + i_xt, xtab, (size_t)ow * 12); std::memcpy(hp + i_yt, ytab, (size_t)oh * 12);
         GCHK(hipMemcpyAsync(g->d_front + o_xt, hp + i_xt, (size_t)ow * 12, hipMemcpyHostToDevice, g->stream));
@@ -713,6 +727,19 @@ extern "C" int mi355_gmc_step_begin(mi355_gmc* g, const uint8_t* bgr, int height
     GCHK(hipMemcpyAsync(hp + g->o_hok, g->d_front + o_ok, np, hipMemcpyDeviceToHost, g->stream));
     g->slot = nslot; g->have_prev = true; g->ph = oh; g->pw = ow;
     g->pending = true; g->oh = oh; g->ow = ow; g->n_lk = n_prev;
+    return 0;
+}
+
+// The frame of the pending step as it sits on the device (dense BGR [height][width][3], uploaded once by mi355_gmc_step_begin): waits -- on
+// the host, ~10 us -- until that upload has landed and hands out the pointer, so that the detector pass of the same frame
+// (mi355_yolo_infer_device) reads this copy instead of uploading its own.  Besides saving the second upload this is what lets the two
+// overlap at all: a second host -> device copy queues up behind the step's device -> host copies, which wait for its Lucas-Kanade launch
+// (measured: the detector's first kernel started when the whole step was over, tools/track_timeline.py).  Valid until the next step_begin.
+extern "C" int mi355_gmc_pending_frame(mi355_gmc* g, const uint8_t** dev_bgr, int* height, int* width) {
+    if (!g || g->host || !(g->pending || g->track_pending) || !g->ev_up || !dev_bgr || !height || !width) return -1;
+    GCHK(hipSetDevice(g->device));
+    GCHK(hipEventSynchronize(g->ev_up));
+    *dev_bgr = g->d_front; *height = g->up_h; *width = g->up_w;
     return 0;
 }
 
@@ -757,6 +784,7 @@ void linear_table(int dn, int sn, std::vector<int>& tab) {
 }
 }  // namespace
 
+static void collect_worker(mi355_gmc* g);
 extern "C" int mi355_gmc_track_begin(mi355_gmc* g, const uint8_t* bgr, int height, int width, int downscale) {
     if (!g || !bgr || height <= 0 || width <= 0 || downscale < 1 || g->track_pending) return -1;
     const int oh = downscale > 1 ? height / downscale : height, ow = downscale > 1 ? width / downscale : width;
@@ -780,12 +808,47 @@ extern "C" int mi355_gmc_track_begin(mi355_gmc* g, const uint8_t* bgr, int heigh
         if (rc) return rc;
     }
     g->track_pending = true; g->t_oh = oh; g->t_ow = ow; g->t_n = n;
+    static const bool async_collect = !getenv("MI355_GMC_ASYNC") || atoi(getenv("MI355_GMC_ASYNC")) != 0;
+    if (!g->host && async_collect) {
+        if (!g->worker.joinable()) g->worker = std::thread(collect_worker, g);
+        { std::lock_guard<std::mutex> lk(g->mu); g->job_ready = true; g->job_done = false; }
+        g->cv.notify_all();
+    }
     return 0;
+}
+
+static int track_collect(mi355_gmc* g, double* H_out);
+static void collect_worker(mi355_gmc* g) {
+    (void)hipSetDevice(g->device);
+    std::unique_lock<std::mutex> lk(g->mu);
+    for (;;) {
+        g->cv.wait(lk, [&] { return g->job_ready || g->worker_stop; });
+        if (g->worker_stop) return;
+        g->job_ready = false;
+        lk.unlock();
+        const int rc = track_collect(g, g->job_H);
+        lk.lock();
+        g->job_rc = rc; g->job_done = true;
+        g->cv.notify_all();
+    }
 }
 
 extern "C" int mi355_gmc_track_finish(mi355_gmc* g, double* H_out) {
     if (!g || !H_out || !g->track_pending) return -1;
+    if (g->worker.joinable()) {
+        std::unique_lock<std::mutex> lk(g->mu);
+        if (g->job_ready || g->job_done) {                      // this step's collect runs (or ran) on the worker
+            g->cv.wait(lk, [&] { return g->job_done; });
+            g->job_done = false; g->track_pending = false;
+            std::memcpy(H_out, g->job_H, sizeof(g->job_H));
+            return g->job_rc;
+        }
+    }
     g->track_pending = false;
+    return track_collect(g, H_out);
+}
+
+static int track_collect(mi355_gmc* g, double* H_out) {
     const int oh = g->t_oh, ow = g->t_ow, n = g->t_n;
     const size_t np = (size_t)oh * ow;
     g->cur_gray.resize(np); g->eig.resize(np); g->ok.resize(np);

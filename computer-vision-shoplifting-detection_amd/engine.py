@@ -150,6 +150,12 @@ class YOLO:
         raise TypeError(f"unsupported source type {type(source).__name__}: pass decoded BGR uint8 frames "
                         f"(frame decode stays on the host, as in the reference's cv2.VideoCapture loop)")
 
+    class _DeviceFrames:
+        """n dense BGR uint8 frames that already sit on the engine's GPU, known by raw pointer (YOLO.track: the copy the tracker's motion
+        compensation uploaded)."""
+        def __init__(self, ptr: int, n: int, h: int, w: int):
+            self.ptr, self.shape = int(ptr), (int(n), int(h), int(w), 3)
+
     def _infer_rows(self, batch, conf, iou, classes, max_det, imgsz, half=None):
         lib = _lib.lib()
         hnd = self._handle(half)
@@ -165,6 +171,9 @@ class YOLO:
             ncls = len(cl)
         cp = counts.ctypes.data_as(C.POINTER(C.c_int))
         with self._lock:
+            if isinstance(batch, YOLO._DeviceFrames):
+                _lib.check(lib.mi355_yolo_infer_device(hnd, batch.ptr, n, h, w, conf, iou, cls_arr, ncls, max_det, imgsz, rows.ctypes.data, max_det, cp))
+                return rows, counts, (h, w)
             if isinstance(batch, torch.Tensor):
                 if not batch.is_cuda:
                     batch = batch.numpy()
@@ -236,6 +245,9 @@ class YOLO:
             imgsz = int(max(imgsz))
         conf = 0.25 if conf is None else float(conf)
         batch, originals = self._as_batch(source)
+        return self._predict_batch(batch, originals, conf, iou, classes, max_det, imgsz, half)
+
+    def _predict_batch(self, batch, originals, conf, iou, classes, max_det, imgsz, half) -> List[Results]:
         rows, counts, shape = self._infer_rows(batch, conf, float(iou), classes, int(max_det), int(imgsz), half)
         t = _lib.Timing()
         _lib.lib().mi355_yolo_last_timing(self._last_handle, C.byref(t))
@@ -277,7 +289,16 @@ class YOLO:
             # the tracker's motion compensation for this frame (frame preparation + optical flow, a stream of its own on the GPU) is
             # enqueued before the detector pass and collected inside tracker.update: the two share the GPU instead of queueing
             self._tracker.gmc.begin(frame)
-            res = self.predict(batch[i:i + 1], conf=conf, **kwargs)[0]
+            # ... and the detector pass reads the copy of the frame that step has just put on the GPU: one upload, and no second host -> device
+            # copy queueing behind the step's device -> host copies (which wait for its Lucas-Kanade launch -- the two used to run one after
+            # the other, tools/track_timeline.py)
+            dev = self._tracker.gmc.pending_device_frame() if isinstance(frame, np.ndarray) and frame.ndim == 3 else None
+            if dev is not None and dev[1:] == tuple(frame.shape[:2]) and not kwargs.get("stream"):
+                imgsz = kwargs.get("imgsz", 640)
+                res = self._predict_batch(YOLO._DeviceFrames(dev[0], 1, dev[1], dev[2]), None, float(conf), kwargs.get("iou", 0.7), kwargs.get("classes"),
+                                          kwargs.get("max_det", 300), int(max(imgsz)) if isinstance(imgsz, (list, tuple)) else int(imgsz), kwargs.get("half"))[0]
+            else:
+                res = self.predict(batch[i:i + 1], conf=conf, **kwargs)[0]
             if originals is not None:
                 res.orig_img = originals[i]
             # trackers/track.py:on_predict_postprocess_end: the tracker steps on EVERY frame (an empty frame still advances

@@ -226,6 +226,18 @@ class GMC:
             raise ValueError(f"mi355_gmc_track_begin: error {rc}")
         self._pending = raw_frame
 
+    def pending_device_frame(self):
+        """(device pointer, height, width) of the frame :meth:`begin` has just uploaded for its step -- dense BGR uint8 on this object's
+        GPU, valid until the next :meth:`begin` -- or None (host object, nothing pending).  ``YOLO.track`` hands it to the detector pass
+        of the same frame: one upload instead of two, and the detector's kernels no longer queue behind this step's copies."""
+        if self.method is None or self._pending is None or self.device is None:
+            return None
+        ptr, h, w = C.c_void_p(), C.c_int(), C.c_int()
+        rc = _lib.lib().mi355_gmc_pending_frame(self._obj(), C.byref(ptr), C.byref(h), C.byref(w))
+        if rc == -2:
+            raise RuntimeError(f"mi355_gmc_pending_frame: HIP error on device {self.device}")
+        return (ptr.value, h.value, w.value) if rc == 0 and ptr.value else None
+
     def apply_batch(self, frames) -> np.ndarray:
         """The warps of n consecutive frames of one video in ONE call -> float64 [n, 2, 3], continuing from the object's previous frame:
         all n frame preparations as one set of launches and all n Lucas-Kanade steps as one launch on the GPU, corner ordering and

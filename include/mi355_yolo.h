@@ -284,6 +284,10 @@ void mi355_gmc_destroy(mi355_gmc* g);
 int  mi355_gmc_step_begin(mi355_gmc* g, const uint8_t* bgr, int height, int width, int oh, int ow, const int* xtab, const int* ytab,
                           double quality, const float* prev_pts, int n_prev, int win, int max_level, int max_iters, double eps, double min_eig);
 int  mi355_gmc_step_finish(mi355_gmc* g, uint8_t* gray_out, float* eig_out, uint8_t* ok_out, float* next_pts, uint8_t* status);
+/* The pending step's frame as it sits on the device (dense BGR [height][width][3]; valid until the next step_begin / track_begin): the
+ * detector pass of the same frame reads this copy through mi355_yolo_infer_device instead of uploading the frame a second time, which is
+ * also what lets the two overlap on the GPU (model.track, /root/reference/model.py:38).  Blocks the host until the upload has landed. */
+int  mi355_gmc_pending_frame(mi355_gmc* g, const uint8_t** dev_bgr, int* height, int* width);
 /* ---- the tracker behind model.track (/root/reference/model.py:38-46), host C++ (csrc/tracker_host.cpp) -------------------------------------
  * Ultralytics' default botsort.yaml tracker, one call per frame: BYTETracker.update's two-stage association on IoU cost fused with the
  * detection score, KalmanFilterXYWH, STrack.multi_gmc's warp of the predicted states, lap.lapjv(extend_cost=True, cost_limit=thresh).

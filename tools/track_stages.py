@@ -26,7 +26,9 @@ for k, f in enumerate(frames):
     t0 = time.perf_counter()
     tr.gmc.begin(f)
     t1 = time.perf_counter()
-    res = model.predict(f[None], conf=0.1)[0]
+    dev = tr.gmc.pending_device_frame()          # as YOLO.track: the detector reads the copy of the frame the step has just uploaded
+    res = (model._predict_batch(YOLO._DeviceFrames(dev[0], 1, dev[1], dev[2]), None, 0.1, 0.7, None, 300, 640, None)[0] if dev is not None
+           else model.predict(f[None], conf=0.1)[0])
     t3 = time.perf_counter()
     warp = tr.gmc.apply(f)
     t4 = time.perf_counter()
