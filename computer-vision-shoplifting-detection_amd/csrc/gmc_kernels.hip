@@ -577,6 +577,7 @@ struct mi355_gmc {
     // its own from the moment track_begin has enqueued the step, i.e. beside the detector pass the caller runs next; track_finish joins it
     std::thread worker; std::mutex mu; std::condition_variable cv;
     bool job_ready = false, job_done = false, worker_stop = false; int job_rc = 0; double job_H[6] = {1, 0, 0, 0, 1, 0};
+    bool job_active = false;                                   // written by the calling thread only: this step's collect belongs to the worker
     // mi355_gmc_track_batch: device buffers of one batch (grow-only) and their pinned mirror
     uint8_t* d_batch = nullptr; size_t batch_cap = 0;
     uint8_t* h_batch = nullptr; size_t hbatch_cap = 0;
@@ -812,6 +813,7 @@ extern "C" int mi355_gmc_track_begin(mi355_gmc* g, const uint8_t* bgr, int heigh
     if (!g->host && async_collect) {
         if (!g->worker.joinable()) g->worker = std::thread(collect_worker, g);
         { std::lock_guard<std::mutex> lk(g->mu); g->job_ready = true; g->job_done = false; }
+        g->job_active = true;
         g->cv.notify_all();
     }
     return 0;
@@ -835,14 +837,12 @@ static void collect_worker(mi355_gmc* g) {
 
 extern "C" int mi355_gmc_track_finish(mi355_gmc* g, double* H_out) {
     if (!g || !H_out || !g->track_pending) return -1;
-    if (g->worker.joinable()) {
+    if (g->job_active) {                                        // this step's collect waits, runs or ran on the worker
         std::unique_lock<std::mutex> lk(g->mu);
-        if (g->job_ready || g->job_done) {                      // this step's collect runs (or ran) on the worker
-            g->cv.wait(lk, [&] { return g->job_done; });
-            g->job_done = false; g->track_pending = false;
-            std::memcpy(H_out, g->job_H, sizeof(g->job_H));
-            return g->job_rc;
-        }
+        g->cv.wait(lk, [&] { return g->job_done; });
+        g->job_done = false; g->job_active = false; g->track_pending = false;
+        std::memcpy(H_out, g->job_H, sizeof(g->job_H));
+        return g->job_rc;
     }
     g->track_pending = false;
     return track_collect(g, H_out);

@@ -292,7 +292,8 @@ class YOLO:
             # ... and the detector pass reads the copy of the frame that step has just put on the GPU: one upload, and no second host -> device
             # copy queueing behind the step's device -> host copies (which wait for its Lucas-Kanade launch -- the two used to run one after
             # the other, tools/track_timeline.py)
-            dev = self._tracker.gmc.pending_device_frame() if isinstance(frame, np.ndarray) and frame.ndim == 3 else None
+            share = os.environ.get("MI355_TRACK_SHARED_FRAME", "1") != "0"            # A/B and tests only
+            dev = self._tracker.gmc.pending_device_frame() if share and isinstance(frame, np.ndarray) and frame.ndim == 3 else None
             if dev is not None and dev[1:] == tuple(frame.shape[:2]) and not kwargs.get("stream"):
                 imgsz = kwargs.get("imgsz", 640)
                 res = self._predict_batch(YOLO._DeviceFrames(dev[0], 1, dev[1], dev[2]), None, float(conf), kwargs.get("iou", 0.7), kwargs.get("classes"),

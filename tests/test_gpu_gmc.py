@@ -221,3 +221,43 @@ def test_batched_steps_are_the_single_steps_bit_for_bit(shape):
     np.testing.assert_array_equal(w2, np.stack([ref.apply(f) for f in small]))
     with pytest.raises(ValueError):
         bat.apply_batch([frames[0], small[0]])
+
+
+def test_pending_frame_is_the_uploaded_frame_and_track_results_do_not_depend_on_sharing_it(monkeypatch):
+    """Round 4: ``model.track`` hands the detector pass the copy of the frame its tracker's motion-compensation step has just uploaded
+    (``mi355_gmc_pending_frame`` -> ``mi355_yolo_infer_device``).  (a) that device copy is the frame, byte for byte, valid while the step is
+    pending and through its collection on the worker thread; (b) the loop's results -- boxes, ids, scores -- are those of the loop that
+    uploads the frame a second time, and of the loop with the step collected on the calling thread (MI355_GMC_ASYNC=0 is read once
+    per process, so that arm is the sharing knob only)."""
+    import torch
+    from cvsd_amd import YOLO
+    from tools import synth
+    h, w = 240, 320
+    big = ((_smooth_noise(h + 40, w + 200, seed=11, sigma=2.0).astype(np.int32) + _smooth_noise(h + 40, w + 200, seed=12, sigma=6.0)) // 2).astype(np.uint8)
+    frames = [np.ascontiguousarray(np.repeat(big[20:20 + h, 7 * k:7 * k + w, None], 3, axis=2)) for k in range(10)]
+    g = gmc.GMC(device=0)
+    g.begin(frames[0])
+    ptr, ph, pw = g.pending_device_frame()
+    assert (ph, pw) == (h, w)
+    back = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    import ctypes as C
+    from cvsd_amd import _lib
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(C.c_void_p(back.data_ptr()), C.c_void_p(ptr), C.c_size_t(h * w * 3), C.c_int(3)) == 0      # device -> device
+    np.testing.assert_array_equal(back.cpu().numpy(), frames[0])
+    g.apply(frames[0])
+    assert g.pending_device_frame() is None                                   # nothing pending any more
+
+    _, sd = synth.synthetic_checkpoint("yolov8n", seed=0)
+    outs = []
+    for share in ("1", "0"):
+        monkeypatch.setenv("MI355_TRACK_SHARED_FRAME", share)
+        model = YOLO.from_state_dict("yolov8n", sd, device=0, batch_chunk=1)
+        rows = []
+        for f in frames:
+            r = model.track(f, persist=True, conf=0.05)[0]
+            rows.append((r.boxes.data.numpy().copy(), None if r.boxes.id is None else r.boxes.id.numpy().copy()))
+        outs.append(rows)
+    for (b1, i1), (b0, i0) in zip(*outs):
+        np.testing.assert_array_equal(b1, b0)
+        assert (i1 is None) == (i0 is None) and (i1 is None or np.array_equal(i1, i0))
