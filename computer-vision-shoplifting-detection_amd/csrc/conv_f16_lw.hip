@@ -260,192 +260,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lw_f16(ConvKArgs a) {
     }
 }
 
-// ---- version 8 (round 4, second step): ONE 512-thread block per CU, a 16 x 32 output tile (two 16 x 16 halves, waves 0-3 / 4-7), the block's
-// weights by LDS-DMA (buffer_load ... lds: no registers, no ds_write pass) into a DOUBLE-buffered region -- item i + 1's 9 * CT KiB land in
-// the other buffer while item i's MFMAs run -- and the halo slice (18 x 34 pixels) register-staged as in version 7.  Against version 7: half the
-// weight bytes per FLOP (one copy feeds 512 pixels), no weight registers (CT 6 at 190 instead of 256), one ds_write pass of 5 instead of 20
-// slots per thread and item.  The price: the two waves of a SIMD belong to ONE block and meet at its barriers, so a unit's epilogue is
-// not covered by a neighbour's MFMAs.
-constexpr int kL2HW = 34, kL2Pix = kLwHalo * kL2HW, kL2XBytes = kL2Pix * 64;
-
-template <int CT>
-__global__ __launch_bounds__(512, 1) void conv3x3_lw2_f16(ConvKArgs a) {
-    constexpr int PT = 4, NF = 9 * CT, NWU = (NF + 7) / 8, NXU = (kL2Pix * 4 + 511) / 512, WBUF = NWU * 8192;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kL2XBytes + 2 * WBUF];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
-    const int half = wave >> 2, wq = wave & 3;
-    const unsigned g = (unsigned)lane >> 4;
-    const int gy = a.cgroups, n_units = a.n_tiles_total * gy, G = (int)gridDim.x;
-    const int my_units = ((int)blockIdx.x < n_units) ? (n_units - 1 - (int)blockIdx.x) / G + 1 : 0;
-    const int cib = a.cib, n_items = my_units * cib;
-    if (n_items == 0) return;
-    auto decode = [&](int j, int& b, int& ty, int& tx, int& cg) {
-        const unsigned u = blockIdx.x + (unsigned)j * (unsigned)G;
-        const unsigned n = (unsigned)n_units, qn = n >> 3, rn = n & 7, x = u & 7;
-        const unsigned logical = (x < rn ? x * (qn + 1) : rn * (qn + 1) + (x - rn) * qn) + (u >> 3);
-        const unsigned t = fastdiv(logical, FastDiv{a.fd_gy.ml, a.fd_gy.mh});
-        cg = (int)(logical - t * (unsigned)gy);
-        const unsigned tq = fastdiv(t, FastDiv{a.fd_tx.ml, a.fd_tx.mh});
-        tx = (int)(t - tq * (unsigned)a.tiles_x);
-        const unsigned bb = fastdiv(tq, FastDiv{a.fd_ty.ml, a.fd_ty.mh});
-        ty = (int)(tq - bb * (unsigned)a.tiles_y);
-        b = (int)bb;
-    };
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, 0x7fffffff, 0x00020000);
-    const unsigned lane16 = (unsigned)lane * 16u;
-    const unsigned q = (unsigned)tid & 3u;
-    const bool qok_last = (cib - 1) * 32 + 8 * (int)q < a.cin4;
-    const int n_wfrag = a.n_ctiles * 9;
-    int jL = 0, kL = 0, wfr0 = 0;
-    unsigned voff[NXU];
-    __amdgpu_buffer_rsrc_t srs = wrsrc;
-    f16x8 px[NXU];
-    bool drop = false;
-    auto prefetch_setup = [&]() {
-        if (kL == 0) {
-            int b, ty, tx, cg;
-            decode(jL, b, ty, tx, cg);
-            srs = __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)a.src + (size_t)b * (size_t)a.img_src), 0, (int)((unsigned)a.img_src * 2u),
-                                                    0x00020000);
-            const int iy0 = ty * kLwTile - 1, ix0 = tx * 2 * kLwTile - 1;
-#pragma unroll
-            for (int u = 0; u < NXU; ++u) {
-                const int pix = u * 128 + (tid >> 2);
-                const int hy = (pix * 1928) >> 16, hx = pix - hy * kL2HW;                        // pix / 34 for pix < 640
-                const int gyy = iy0 + hy, gxx = ix0 + hx;
-                const bool ok = pix < kL2Pix && (unsigned)gyy < (unsigned)a.Hin && (unsigned)gxx < (unsigned)a.Win;
-                voff[u] = ok ? (unsigned)(__mul24(__mul24(gyy, a.Win) + gxx, a.src_cs) * 2) + q * 16u : kOOB;
-            }
-            wfr0 = cg * CT * 9;
-        }
-        drop = (kL == cib - 1) && !qok_last;
-    };
-    auto x_load = [&](int u) {
-        px[u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(srs, (int)(drop ? kOOB : voff[u]), kL * 64, 0));
-    };
-    auto w_dma = [&](int u, int buf) {                         // weight fragment f = 8 u + wave of item (jL, kL) -> buffer `buf`, 1 KiB per wave-instruction
-        const int f = 8 * u + wave;
-        if (f < NF) {
-            const int fi = min(wfr0 + f, n_wfrag - 1);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(lds + kL2XBytes + buf * WBUF + f * 1024), 16, (int)lane16,
-                                                     (fi * cib + kL) * 1024, 0, 0);
-        }
-    };
-    auto prefetch_advance = [&]() {
-        if (jL + 1 < my_units || kL + 1 < cib) { if (++kL == cib) { kL = 0; ++jL; } }
-    };
-    const unsigned cx = (unsigned)(tid >> 2) * 64u + ((q ^ ((((unsigned)tid >> 4) & 1u) << 1)) * 16u);
-    auto commit = [&]() {
-#pragma unroll
-        for (int u = 0; u < NXU; ++u)
-            if (u * 128 + (tid >> 2) < kL2Pix) *(f16x8*)(lds + cx + u * 8192) = px[u];
-    };
-    const unsigned pl = (unsigned)(4 * wq * kL2HW + 16 * half + (lane & 15));
-    const unsigned xbase = pl * 64u + (g & 1u) * 16u;
-    unsigned swm = 0;
-#pragma unroll
-    for (int i = 0; i < 18; ++i) swm |= ((((pl + (unsigned)((i / 3) * kL2HW + (i % 3))) >> 2) ^ (g >> 1)) & 1u) << i;
-    auto xfrag = [&](int r, int tc) -> f16x8 {
-        unsigned sw = swm;
-        if (CT >= 6) asm volatile("" : "+v"(sw));
-        const unsigned off = xbase + (((sw >> (r * 3 + tc)) & 1u) << 5);
-        return *(const f16x8*)__builtin_assume_aligned(lds + off + (r * kL2HW + tc) * 64, 16);
-    };
-    f32x4 acc[CT][PT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    auto compute = [&](int cur) {                              // item in buffer `cur`; the next item's loads and DMAs go out between its micro-steps
-        constexpr int M = 9 * CT;
-        const unsigned wbase = (unsigned)kL2XBytes + (unsigned)cur * (unsigned)WBUF + lane16;
-        auto wfrag = [&](int m) -> f16x8 { return *(const f16x8*)__builtin_assume_aligned(lds + wbase + ((m % CT) * 9 + m / CT) * 1024, 16); };
-        f16x8 xf[2][PT], wr[3];
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) xf[0][pt] = xfrag(pt, 0);
-        wr[0] = wfrag(0);
-        wr[1] = wfrag(1);
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int m = t * CT + ct;
-                if (m + 2 < M) wr[(m + 2) % 3] = wfrag(m + 2);
-                if (t + 1 < 9) {
-#pragma unroll
-                    for (int pt = ct * PT / CT; pt < (ct + 1) * PT / CT; ++pt) xf[(t + 1) & 1][pt] = xfrag(pt + (t + 1) / 3, (t + 1) % 3);
-                }
-                if (m < NXU) x_load(m);
-                else if (m < NXU + NWU) w_dma(m - NXU, cur ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int pt = 0; pt < PT; ++pt)
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[m % 3], xf[t & 1][pt], acc[ct][pt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        static_assert(NXU + NWU <= M, "one load per micro-step");
-    };
-    auto epilogue = [&](int j) {
-        int b, ty, tx, cg;
-        decode(j, b, ty, tx, cg);
-        const int ct0 = cg * CT;
-        const OutF16 o = make_out_f16(a.dst, a.dst_cs, a.img_dst, a.res, a.res_cs, a.img_res, b, a.Cout, a.act, a.out_f32);
-        int pixi[PT];
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            const int oy = ty * kLwTile + 4 * wq + pt, ox = tx * 2 * kLwTile + 16 * half + (lane & 15);
-            pixi[pt] = (oy < a.Hout && ox < a.Wout) ? __mul24(oy, a.Wout) + ox : -1;
-        }
-        f32x4 bias4[CT];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
-            bias4[ct] = *(const f32x4*)(a.bias + tile_cout0(ctile, lane >> 4, conv_f16_pairs(a.Cout)));
-        }
-        store_tiles_f16_v2<PT, CT>(o, acc, bias4, lane, ct0, pixi);
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    };
-
-    // item 0: halo slice into registers, weights into buffer 0
-    prefetch_setup();
-#pragma unroll
-    for (int u = 0; u < NXU; ++u) x_load(u);
-#pragma unroll
-    for (int u = 0; u < NWU; ++u) w_dma(u, 0);
-    prefetch_advance();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int jC = 0, kC = 0, jE = -1;
-    for (int i = 0;; ++i) {
-        if (i < n_items) commit();                         // item i's halo slice: registers -> LDS
-        if (jE >= 0) { epilogue(jE); jE = -1; }
-        if (i == n_items) break;
-        prefetch_setup();                                  // item i + 1 (beyond the last item: the last one again, harmlessly)
-        __syncthreads();                                   // nothing is in flight here: the previous iteration ended with vmcnt(0)
-        compute(i & 1);
-        prefetch_advance();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of item i + 1 have landed (a DMA is ordered for a reader only by the
-        __syncthreads();                                   // issuer's vmcnt and a barrier the reader has passed); every wave is done reading item i
-        if (kC == cib - 1) jE = jC;
-        if (++kC == cib) { kC = 0; ++jC; }
-    }
-}
-
 typedef void (*KernelFn)(ConvKArgs);
 
 }  // namespace
-
-// version-8 launch plans (512-thread blocks): CT 3, 4 or 6
-const void* pick_conv_lw2_f16(int CT) {
-    if (CT == 3) return (const void*)(KernelFn)&conv3x3_lw2_f16<3>;
-    if (CT == 4) return (const void*)(KernelFn)&conv3x3_lw2_f16<4>;
-    if (CT == 6) return (const void*)(KernelFn)&conv3x3_lw2_f16<6>;
-    return nullptr;
-}
 
 // version-7 launch plans: CT cout tiles per block (48 / 64 / 96 couts)
 const void* pick_conv_lw_f16(int CT) {

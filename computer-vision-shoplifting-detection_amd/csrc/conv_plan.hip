@@ -202,14 +202,6 @@ std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int ci
             Plan p7{CT, 4, 16, 16, 16, 0, 0.0, 7, 0, 4};
             p7.cost = (double)nblk * CT / n_ctiles * (double)tiles * 256.0 / ((double)W * H) * 0.7;
             out.push_back(p7);
-            // v8: the same with ONE 512-thread block per CU on a 16 x 32 output tile and the weights by LDS-DMA into a double-buffered region
-            static const int use_v8 = env_int("MI355_CONV_V8", 1);
-            if (use_v8 && W >= 24) {
-                const long tiles8 = (long)((W + 31) / 32) * ((H + 15) / 16);
-                Plan p8{CT, 4, 32, 16, 16, 0, 0.0, 8, 0, 4};
-                p8.cost = (double)nblk * CT / n_ctiles * (double)tiles8 * 512.0 / ((double)W * H) * 0.7;
-                out.push_back(p8);
-            }
         }
     }
     if (ks == 1 && have_zero_page) {        // streaming pointwise kernel (needs the zero page as well): CT x PT register tiles
@@ -302,7 +294,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     } else {
         a.Hin = c.Hin; a.Win = c.Win; a.Hout = c.Hout; a.Wout = c.Wout;
     }
-    KernelFn fn = half ? (p.version == 7 ? (KernelFn)pick_conv_lw_f16(p.CT) : p.version == 8 ? (KernelFn)pick_conv_lw2_f16(p.CT) : p.version == 4 ? (KernelFn)pick_conv_pipe_f16(p.CT, p.WP, (c.Cin + 1) / 2 <= p.ck, p.ck > 64)
+    KernelFn fn = half ? (p.version == 7 ? (KernelFn)pick_conv_lw_f16(p.CT) : p.version == 4 ? (KernelFn)pick_conv_pipe_f16(p.CT, p.WP, (c.Cin + 1) / 2 <= p.ck, p.ck > 64)
                           : p.f2 ? (KernelFn)pick_conv_fused_f16(c.stride, p.CT, p.WP, p.PT)
                                  : (p.version == 1 && (p.PT == 1 || p.PT == 2)) ? (KernelFn)pick_conv_small_f16(c.k, c.stride, p.CT, p.WP, p.PT)
                                  : (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.version == 3 ? p.buf_floats : p.PT))
@@ -321,7 +313,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
         if (c.f2_lead_c) { a.lead = c.f2_lead; a.lead_cs = c.f2_lead_cs; a.lead_cib = c.f2_lead_c / 16; a.cib2 += a.lead_cib; }
     }
     if (half && p.version == 4) a.lds_buf_floats = 0;
-    if (half && (p.version == 1 || p.version == 7 || p.version == 8) && !p.f2) { static const int ex = env_int("MI355_F16_EXP", 0); a.lds_buf_floats = ex; }
+    if (half && (p.version == 1 || p.version == 7) && !p.f2) { static const int ex = env_int("MI355_F16_EXP", 0); a.lds_buf_floats = ex; }
     a.TW = p.TW; a.TH = p.TH;
     a.tiles_x = (a.Wout + p.TW - 1) / p.TW; a.tiles_y = (a.Hout + p.TH - 1) / p.TH;
     a.TWin = (p.TW - 1) * c.stride + c.k;
@@ -354,14 +346,13 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     }
     out->grid_y = (unsigned)((a.n_ctiles + p.CT * WC * a.cgroups - 1) / (p.CT * WC * a.cgroups));
     unsigned v7_gy = 1;
-    if (p.version == 7 || p.version == 8) {
-        // persistent: as many blocks as stay resident (v7: two 256-thread blocks per CU, v8: one 512-thread block), each walks units blockIdx.x, + gridDim.x, ...; unit = (tile, cout group)
+    if (p.version == 7) {
+        // persistent: as many blocks as stay resident (two per CU), each walks units blockIdx.x, + gridDim.x, ...; unit = (tile, cout group)
         if (c.pad != 1) return "conv: the LDS-weights kernel needs pad 1";
         v7_gy = (unsigned)((a.n_ctiles + p.CT - 1) / p.CT);
         a.cgroups = (int)v7_gy;
         int per_cu = 0;
-        const int v78_threads = p.version == 8 ? 512 : 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, v78_threads, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = p.version == 8 ? 1 : 2; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, 256, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 2; }
         const unsigned long long units = (unsigned long long)a.n_tiles_total * v7_gy;
         if (units >= (1u << 24)) return "conv: more than 2^24 work units in one launch";
         out->grid_x = (unsigned)std::min<unsigned long long>(units, 256ull * (unsigned)per_cu);
@@ -370,7 +361,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     }
     if ((unsigned long long)out->grid_x * out->grid_y >= (1u << 24)) return "conv: more than 2^24 blocks in one launch";
     a.fd_tx = make_fastdiv((unsigned)std::max(1, a.tiles_x)); a.fd_ty = make_fastdiv((unsigned)std::max(1, a.tiles_y));
-    a.fd_gy = make_fastdiv(std::max(1u, (p.version == 7 || p.version == 8) ? v7_gy : out->grid_y));
+    a.fd_gy = make_fastdiv(std::max(1u, p.version == 7 ? v7_gy : out->grid_y));
     if (!half && (p.version == 1 || p.f2)) {
         // conv_igemm_f32 addresses one image of each slice through a buffer descriptor with 32-bit byte offsets (a pointwise
         // launch sees the flattened batch as one image), and lanes / pad channels whose store must be DROPPED are given the
@@ -390,7 +381,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
         a.st_nseg = row_slots >= 256 ? (row_slots + 255) / 256 : 1;
         a.inv_row_slots = 1.0f / (float)row_slots;
     }
-    if (half && (p.version == 1 || p.version == 7 || p.version == 8 || p.f2)) {
+    if (half && (p.version == 1 || p.version == 7 || p.f2)) {
         // conv_igemm_f16 (round 3): source / destination / residual images behind buffer descriptors with 32-bit byte offsets and
         // the drop marker 0x80000000 -- every image must stay below 2^31 bytes, and a source row below 2^24 bytes (24-bit multiply)
         const long long lim = 1ll << 31;
@@ -403,7 +394,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     out->lds = p.lds;
     out->a = a;
     out->CT = p.CT; out->WP = p.WP; out->version = p.version;
-    out->PT = p.version == 3 ? p.buf_floats : (p.PT ? p.PT : (p.CT == 5 ? 3 : 4)); out->threads = p.version == 8 ? 512 : 256;
+    out->PT = p.version == 3 ? p.buf_floats : (p.PT ? p.PT : (p.CT == 5 ? 3 : 4)); out->threads = 256;
     if (p.version == 3) {          // streaming 1x1: block = 4 waves x PT pixel tiles, grid.y over cout blocks of CT tiles
         const int PT = p.buf_floats;
         out->grid_x = (unsigned)((a.Wout + 4 * PT * 16 - 1) / (4 * PT * 16));
