@@ -123,6 +123,8 @@ SIGNATURES = {
     "mi355_gmc_track_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mi355_gmc_track_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi355_gmc_track_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mi355_gmc_batch_frames": (C.c_int, [C.c_void_p, C.c_ulonglong, C.c_int, C.POINTER(C.c_void_p), _i32p, _i32p, _i32p, C.POINTER(C.c_longlong)]),
+    "mi355_gmc_batch_seq": (C.c_ulonglong, [C.c_void_p]),
     "mi355_gmc_track_reset": (C.c_int, [C.c_void_p]),
     "mi355_gmc_track_state": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, C.c_void_p, C.c_void_p, C.c_int]),
     "mi355_op_stem": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,

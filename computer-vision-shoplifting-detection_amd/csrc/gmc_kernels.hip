@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -577,6 +578,9 @@ struct mi355_gmc {
     // its own from the moment track_begin has enqueued the step, i.e. beside the detector pass the caller runs next; track_finish joins it
     std::thread worker; std::mutex mu; std::condition_variable cv;
     bool job_ready = false, job_done = false, worker_stop = false; int job_rc = 0; double job_H[6] = {1, 0, 0, 0, 1, 0};
+    // mi355_gmc_batch_frames: the frames of the batch a (concurrent) mi355_gmc_track_batch call has uploaded
+    hipEvent_t ev_batch_up = nullptr; unsigned long long batch_up_seq = 0; int batch_n = 0, batch_h = 0, batch_w = 0; size_t batch_fstride = 0;
+    bool batch_failed = false;
     bool job_active = false;                                   // written by the calling thread only: this step's collect belongs to the worker
     // mi355_gmc_track_batch: device buffers of one batch (grow-only) and their pinned mirror
     uint8_t* d_batch = nullptr; size_t batch_cap = 0;
@@ -618,6 +622,7 @@ extern "C" void mi355_gmc_destroy(mi355_gmc* g) {
     (void)hipSetDevice(g->device);
     if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
     if (g->ev_up) (void)hipEventDestroy(g->ev_up);
+    if (g->ev_batch_up) (void)hipEventDestroy(g->ev_batch_up);
     if (g->d_front) (void)hipFree(g->d_front);
     for (int i = 0; i < 2; ++i) if (g->d_pyr[i]) (void)hipFree(g->d_pyr[i]);
     if (g->d_pts) (void)hipFree(g->d_pts); if (g->d_next) (void)hipFree(g->d_next); if (g->d_status) (void)hipFree(g->d_status);
@@ -934,8 +939,8 @@ extern "C" int mi355_gmc_track_batch(mi355_gmc* g, const uint8_t* const* frames,
     const bool cont = g->have_prev_pts && g->prev_h == oh && g->prev_w == ow && g->have_prev && g->ph == oh && g->pw == ow && g->pyr_cap >= pyr_bytes;
     // device: [frames n x nb | pyramids (n + 1) x pyr_bytes | eig n x np x 4 | ok n x np | x table | y table | max n x 4 | pts n x kMaxCorners x 8 |
     //          next (same) | status n x kMaxCorners | counts n x 4]
-    const size_t fstride = al(nb);
-    const size_t o_pyr = (size_t)n * fstride, o_eig = o_pyr + (size_t)(n + 1) * pyr_bytes, o_ok = o_eig + al((size_t)n * np * 4), o_xt = o_ok + al((size_t)n * np),
+    const size_t fstride = (nb % 16 == 0) ? nb : al(nb);       // dense frames when 16-byte aligned: the detector may read them in place (mi355_gmc_batch_frames)
+    const size_t o_pyr = al((size_t)n * fstride), o_eig = o_pyr + (size_t)(n + 1) * pyr_bytes, o_ok = o_eig + al((size_t)n * np * 4), o_xt = o_ok + al((size_t)n * np),
                  o_yt = o_xt + al((size_t)ow * 12), o_max = o_yt + al((size_t)oh * 12), o_pts = o_max + al((size_t)n * 4),
                  o_next = o_pts + al((size_t)n * kMaxCorners * 8), o_st = o_next + al((size_t)n * kMaxCorners * 8), o_cnt = o_st + al((size_t)n * kMaxCorners),
                  d_total = o_cnt + al((size_t)n * 4);
@@ -945,7 +950,7 @@ extern "C" int mi355_gmc_track_batch(mi355_gmc* g, const uint8_t* const* frames,
         GCHK(hipMalloc(&g->d_batch, d_total)); g->batch_cap = d_total;
     }
     // pinned: [frames | tables | eig | ok | pts | next | status | counts | last gray]
-    const size_t p_xt = (size_t)n * fstride, p_yt = p_xt + al((size_t)ow * 12), p_eig = p_yt + al((size_t)oh * 12), p_ok = p_eig + al((size_t)n * np * 4),
+    const size_t p_xt = al((size_t)n * fstride), p_yt = p_xt + al((size_t)ow * 12), p_eig = p_yt + al((size_t)oh * 12), p_ok = p_eig + al((size_t)n * np * 4),
                  p_pts = p_ok + al((size_t)n * np), p_next = p_pts + al((size_t)n * kMaxCorners * 8), p_st = p_next + al((size_t)n * kMaxCorners * 8),
                  p_cnt = p_st + al((size_t)n * kMaxCorners), p_gray = p_cnt + al((size_t)n * 4), h_total = p_gray + al(np);
     if (g->hbatch_cap < h_total) {
@@ -954,8 +959,20 @@ extern "C" int mi355_gmc_track_batch(mi355_gmc* g, const uint8_t* const* frames,
         GCHK(hipHostMalloc(&g->h_batch, h_total)); g->hbatch_cap = h_total;
     }
     uint8_t* D = g->d_batch; uint8_t* P = g->h_batch;
-    for (int f = 0; f < n; ++f) std::memcpy(P + (size_t)f * fstride, frames[f], nb);
+    {   // frames -> pinned staging on a few threads (64 frames of 320 x 240 are 14.7 MB: 2.5 ms on one core, a third of this call)
+        const int nt = std::max(1, std::min(std::min(8, n), (int)std::thread::hardware_concurrency()));
+        if (nt <= 1 || (size_t)n * nb < (1u << 20)) { for (int f = 0; f < n; ++f) std::memcpy(P + (size_t)f * fstride, frames[f], nb); }
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { for (int f = t; f < n; f += nt) std::memcpy(P + (size_t)f * fstride, frames[f], nb); });
+            for (auto& t : th) t.join();
+        }
+    }
     GCHK(hipMemcpyAsync(D, P, (size_t)n * fstride, hipMemcpyHostToDevice, g->stream));
+    if (!g->ev_batch_up) GCHK(hipEventCreateWithFlags(&g->ev_batch_up, hipEventDisableTiming));
+    GCHK(hipEventRecord(g->ev_batch_up, g->stream));
+    { std::lock_guard<std::mutex> lk(g->mu); g->batch_n = n; g->batch_h = height; g->batch_w = width; g->batch_fstride = fstride; ++g->batch_up_seq; }
+    g->cv.notify_all();
     if (resize) {
         std::memcpy(P + p_xt, g->xt.data(), (size_t)ow * 12); std::memcpy(P + p_yt, g->yt.data(), (size_t)oh * 12);
         GCHK(hipMemcpyAsync(D + o_xt, P + p_xt, (size_t)ow * 12, hipMemcpyHostToDevice, g->stream));
@@ -1051,6 +1068,32 @@ extern "C" int mi355_gmc_track_batch(mi355_gmc* g, const uint8_t* const* frames,
     g->prev_gray.assign(P + p_gray, P + p_gray + np);
     g->prev_h = oh; g->prev_w = ow; g->have_prev_pts = true;
     return 0;
+}
+
+// The frames of the batch that a mi355_gmc_track_batch call -- running on ANOTHER thread, or already returned -- has uploaded: blocks until that
+// call has issued its upload (at most timeout_ms) and the upload has landed, then hands out the device pointer (frame f at dev + f * stride).
+// The detector pass of the same batch reads them in place (mi355_yolo_infer_device when stride == height * width * 3): one staging copy and one
+// upload per batch instead of two of each.  Each upload is handed out once; valid until the next mi355_gmc_track_batch call on the object.
+// after_seq: the value of mi355_gmc_batch_seq taken BEFORE that call was started (uploads are numbered; an older one is never handed out).
+// Returns 0, 1 on timeout / nothing new, -1 on bad arguments, -2 on a HIP error.
+extern "C" int mi355_gmc_batch_frames(mi355_gmc* g, unsigned long long after_seq, int timeout_ms, const uint8_t** dev, int* n, int* height, int* width,
+                                      long long* stride) {
+    if (!g || g->host || !dev || !n || !height || !width || !stride) return -1;
+    {
+        std::unique_lock<std::mutex> lk(g->mu);
+        if (!g->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms), [&] { return g->batch_up_seq > after_seq; })) return 1;
+        *n = g->batch_n; *height = g->batch_h; *width = g->batch_w; *stride = (long long)g->batch_fstride;
+    }
+    GCHK(hipSetDevice(g->device));
+    GCHK(hipEventSynchronize(g->ev_batch_up));
+    *dev = g->d_batch;
+    return 0;
+}
+
+extern "C" unsigned long long mi355_gmc_batch_seq(mi355_gmc* g) {
+    if (!g) return 0;
+    std::lock_guard<std::mutex> lk(g->mu);
+    return g->batch_up_seq;
 }
 
 // Forget the previous frame (GMC.reset_params); a pending step is collected and dropped.

@@ -247,6 +247,20 @@ class YOLO:
         batch, originals = self._as_batch(source)
         return self._predict_batch(batch, originals, conf, iou, classes, max_det, imgsz, half)
 
+    def detect_rows(self, batch, conf: float = 0.25, iou: float = 0.7, classes=None, max_det: int = 300, imgsz: int = 640, half=None):
+        """``Results.boxes.data`` of every frame of ``batch`` -- float32 [M, 6] rows x1, y1, x2, y2, conf, cls -- and the frames' (h, w),
+        without building the Results objects (a sweep reads nothing else: cvsd_amd/sweep.py).  ``batch``: what :meth:`predict` takes
+        after stacking, or frames already on the engine's GPU (:class:`_DeviceFrames`)."""
+        rows, counts, shape = self._infer_rows(batch, float(conf), float(iou), classes, int(max_det), int(imgsz), half)
+        out = []
+        for i in range(len(counts)):
+            r = rows[i, :counts[i]]
+            d = np.empty((len(r), 6), np.float32)
+            d[:, :5] = r[:, :5]
+            d[:, 5] = r[:, 5:6].view(np.int32)[:, 0]
+            out.append(d)
+        return out, shape
+
     def _predict_batch(self, batch, originals, conf, iou, classes, max_det, imgsz, half) -> List[Results]:
         rows, counts, shape = self._infer_rows(batch, conf, float(iou), classes, int(max_det), int(imgsz), half)
         t = _lib.Timing()

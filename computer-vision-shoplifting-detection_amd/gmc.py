@@ -226,6 +226,25 @@ class GMC:
             raise ValueError(f"mi355_gmc_track_begin: error {rc}")
         self._pending = raw_frame
 
+    def batch_seq(self) -> int:
+        """number of the last batch upload of this object (take it BEFORE starting :meth:`apply_batch` on another thread)"""
+        return int(_lib.lib().mi355_gmc_batch_seq(self._obj())) if (self.method is not None and self.device is not None) else 0
+
+    def batch_device_frames(self, after_seq: int, timeout_ms: int = 2000):
+        """(device pointer, n, height, width) of the frames an :meth:`apply_batch` call -- running on another thread, started after
+        :meth:`batch_seq` returned ``after_seq`` -- has uploaded for its batch, or None (host object; nothing uploaded within the timeout;
+        frames not dense on the device).  ``sweep.process_clip`` runs the detector pass of the batch on them while ``apply_batch`` carries
+        on: one staging copy and one upload instead of two."""
+        if self.method is None or self.device is None:
+            return None
+        ptr, n, h, w, stride = C.c_void_p(), C.c_int(), C.c_int(), C.c_int(), C.c_longlong()
+        rc = _lib.lib().mi355_gmc_batch_frames(self._obj(), int(after_seq), int(timeout_ms), C.byref(ptr), C.byref(n), C.byref(h), C.byref(w), C.byref(stride))
+        if rc == -2:
+            raise RuntimeError(f"mi355_gmc_batch_frames: HIP error on device {self.device}")
+        if rc != 0 or not ptr.value or stride.value != h.value * w.value * 3:
+            return None
+        return ptr.value, n.value, h.value, w.value
+
     def pending_device_frame(self):
         """(device pointer, height, width) of the frame :meth:`begin` has just uploaded for its step -- dense BGR uint8 on this object's
         GPU, valid until the next :meth:`begin` -- or None (host object, nothing pending).  ``YOLO.track`` hands it to the detector pass

@@ -94,28 +94,56 @@ def process_clip(model, cap, batch: int = 64, conf: float = 0.1, classes=(0,), *
     """All tracked boxes of one clip: array [rows, 6] = frame number (1-based), local track id, xywhn (centre x, centre y,
     w, h).  Detection is batched; the tracker sees the frames one by one, in order (model.py:38 semantics).
 
-    Two things run side by side: the detector pass of batch k + 1 (a worker thread inside the engine's C call) and, on this thread, the
-    tracker's work on batch k -- first the motion compensation of all its frames as ONE batched GPU step on a stream of its own, then
-    the association frame by frame (host C++)."""
+    Per batch three things run side by side (round 4): the tracker's motion compensation of all its frames as ONE batched GPU step
+    (``gmc.apply_batch``, a thread of its own inside one C call), the detector pass of the SAME batch -- reading the frames that step has
+    just uploaded (``gmc.batch_device_frames`` -> ``mi355_yolo_infer_device``): one staging copy and one upload per batch instead of two of
+    each, no ``np.stack``, no Results objects -- and, on this thread, the association of the PREVIOUS batch frame by frame (host C++).
+    A clip's last, partial batch is padded for the detector only (power-of-two bucket) and takes the host path."""
+    import os
     from concurrent.futures import ThreadPoolExecutor
+    from .engine import YOLO
     from .tracker import BYTETracker
     tracker = BYTETracker(gmc_device=getattr(model, "device", None))     # motion compensation on the engine's GPU (csrc/gmc_kernels.hip)
     blocks: List[np.ndarray] = []
+    gmc_on = tracker.gmc.method is not None
+    share = gmc_on and tracker.gmc.device is not None and hasattr(model, "detect_rows") and os.environ.get("MI355_SWEEP_SHARED_FRAMES", "1") != "0"     # A/B and tests only
+    kw = dict(conf=conf, classes=list(classes), **predict_kw)
 
-    def detect(buf):
-        # a clip's last batch is filled up to the next power of two with copies of its last frame (their results are dropped)
-        stack = np.stack(buf + [buf[-1]] * (pad_bucket(len(buf), batch) - len(buf)))
-        return model.predict(stack, conf=conf, classes=list(classes), **predict_kw)[:len(buf)]
+    def rows_of(frames):
+        if hasattr(model, "detect_rows"):
+            return model.detect_rows(frames, **kw)
+        res = model.predict(frames, **kw)                      # any object with the Ultralytics call surface
+        return [r.boxes.data.numpy() for r in res], (res[0].orig_shape if res else tuple(frames.shape[1:3]))
 
-    def track(fut, nums, buf):
-        # the camera-motion warps of the whole batch in one call (all frame preparations as one set of launches, all Lucas-Kanade steps
-        # as one launch: gmc.apply_batch), beside the detector pass of the NEXT batch; then the association, frame by frame
-        warps = tracker.gmc.apply_batch(buf) if tracker.gmc.method is not None else [None] * len(buf)
-        results = fut.result()
-        for n, res, warp in zip(nums, results, warps):
-            tracks = tracker.update(res.boxes.data.numpy(), warp=warp)      # every frame, empty ones too (frame_id / lost-track ageing)
+    log_t = os.environ.get("MI355_SWEEP_LOG") == "1"             # per-batch stage times on stderr (diagnostics)
+
+    def timed(name, fn, *a):
+        if not log_t:
+            return fn(*a)
+        import sys, time
+        t0 = time.perf_counter()
+        r = fn(*a)
+        print(f"[sweep] {name} {1e3 * (time.perf_counter() - t0):.2f} ms (start {1e3 * (t0 % 10):.1f})", file=sys.stderr)
+        return r
+
+    def detect(buf, after_seq):
+        n = len(buf)
+        if share and pad_bucket(n, batch) == n:
+            dev = tracker.gmc.batch_device_frames(after_seq)
+            if dev is not None and dev[1] == n and dev[2:] == tuple(buf[0].shape[:2]):
+                return model.detect_rows(YOLO._DeviceFrames(dev[0], n, dev[2], dev[3]), **kw)
+        # host path: a clip's last batch is filled up to the next power of two with copies of its last frame (their results are dropped)
+        stack = np.stack(buf + [buf[-1]] * (pad_bucket(n, batch) - n))
+        dets, shape = rows_of(stack)
+        return dets[:n], shape
+
+    def associate(nums, fut_d, fut_g):
+        dets, shape = fut_d.result()
+        warps = fut_g.result() if fut_g is not None else [None] * len(nums)
+        for n, det, warp in zip(nums, dets, warps):
+            tracks = tracker.update(det, warp=warp)            # every frame, empty ones too (frame_id / lost-track ageing)
             if len(tracks):                                    # `if not boxes.is_track: return` otherwise (model.py:45)
-                blocks.append(track_rows_xywhn(tracks, n, res.orig_shape))
+                blocks.append(track_rows_xywhn(tracks, n, shape))
 
     def batches():
         buf, nums = [], []
@@ -132,15 +160,21 @@ def process_clip(model, cap, batch: int = 64, conf: float = 0.1, classes=(0,), *
         if buf:
             yield nums, buf
 
-    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="detect") as pool:
+    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="gmc") as pool_g, ThreadPoolExecutor(max_workers=1, thread_name_prefix="detect") as pool_d:
         pending = None
         for nums, buf in batches():
-            fut = pool.submit(detect, buf)                     # batch k + 1 on the detector ...
+            # the detector pass of batch k reads batch k's frames out of the motion-compensation step's device buffer: batch k - 1's detector
+            # pass is over (its future was collected below before this point of the previous iteration's successor) ...
             if pending is not None:
-                track(*pending)                                # ... while batch k is tracked
-            pending = (fut, nums, buf)
+                pending[1].result()
+            seq = tracker.gmc.batch_seq() if share else 0
+            fut_g = pool_g.submit(timed, "gmc", tracker.gmc.apply_batch, buf) if gmc_on else None
+            fut_d = pool_d.submit(timed, "detect", detect, buf, seq)
+            if pending is not None:
+                timed("associate", associate, *pending)       # ... and batch k - 1 is associated while the GPU works on batch k
+            pending = (nums, fut_d, fut_g)
         if pending is not None:
-            track(*pending)
+            associate(*pending)
     cap.release()
     return np.concatenate(blocks) if blocks else np.zeros((0, 6), np.float64)
 

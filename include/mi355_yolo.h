@@ -326,6 +326,14 @@ int  mi355_gmc_track_finish(mi355_gmc* g, double* H_out);
  * preparations as one set of launches, all n Lucas-Kanade steps as one launch, corner ordering and RANSAC on host threads.  H_out [n][6] is
  * bit for bit what n track_begin / track_finish steps return; the object's previous frame is continued from and left behind. */
 int  mi355_gmc_track_batch(mi355_gmc* g, const uint8_t* const* frames, int n, int height, int width, int downscale, double* H_out);
+/* The frames a mi355_gmc_track_batch call (on another thread, or returned) has uploaded, for the detector pass of the same batch to read in
+ * place: waits up to timeout_ms for an upload numbered above after_seq (= mi355_gmc_batch_seq taken before that call was started), then
+ * frame f is at dev + f * stride on the object's GPU (dense BGR; stride == height * width * 3 when that is a multiple of 16).  Valid until
+ * the next mi355_gmc_track_batch on the object.  0 = ok, 1 = nothing new within the timeout (cvsd_amd/sweep.py: the production sweep of
+ * /root/reference/preprocess.py:36-47). */
+unsigned long long mi355_gmc_batch_seq(mi355_gmc* g);
+int  mi355_gmc_batch_frames(mi355_gmc* g, unsigned long long after_seq, int timeout_ms, const uint8_t** dev, int* n, int* height, int* width,
+                            long long* stride);
 int  mi355_gmc_track_reset(mi355_gmc* g);
 int  mi355_gmc_track_state(const mi355_gmc* g, int* oh, int* ow, int* n_pts, uint8_t* gray_out, float* pts_out, int pts_cap);
 /* The u8 stem: letterboxed BGR frames -> (x/255, RGB) -> conv k x k stride s (pad k/2, or 2 for k=6) + bias + SiLU. */
