@@ -260,9 +260,174 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lw_f16(ConvKArgs a) {
     }
 }
 
+// ---- version 9 (round 4): pointwise convs in the same style ---------------------------------------------------------------------------
+// What-if runs (profiles/r04_pointwise_whatif.txt) showed the half-mode 1x1 launches spending half their time in an input-staging phase nothing
+// overlaps, and a fifth waiting for weight fragments every wave fetches for itself.  Here a block = 4 waves x 64 pixels (PT = 4) = 256
+// flattened pixels x CT * 16 couts; the waves share the weights, which travel through a DOUBLE-buffered LDS region in chunks of KC = 4
+// k-blocks (registers -> LDS inside the MFMA phase of the previous chunk: one barrier per chunk, no phase of its own); a wave's own pixels
+// need no LDS at all -- their B fragments (64 contiguous bytes per pixel and k-block) stream from global memory into a register ring
+// one chunk (KC k-blocks) ahead of the MFMAs, across chunk AND unit boundaries (persistent blocks, (pixel tile, cout group) units in the XCD-aware order).
+// Same single accumulation chain over ascending k-blocks as every other half-mode plan: the same bits.
+template <int CT>
+__global__ __launch_bounds__(256, 2) void conv1x1_lw_f16(ConvKArgs a) {
+    constexpr int PT = 4, KC = 4, NFW = CT * KC, NWU = (NFW + 3) / 4, WBUF = NWU * 4096;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * WBUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
+    const unsigned g = (unsigned)lane >> 4;
+    const int total = a.Wout;                                  // flattened pixels (batch x height x width)
+    const int gy = a.cgroups, n_units = a.n_tiles_total * gy, G = (int)gridDim.x;
+    const int my_units = ((int)blockIdx.x < n_units) ? (n_units - 1 - (int)blockIdx.x) / G + 1 : 0;
+    const int cib = a.cib, n_chunks = (cib + KC - 1) / KC;
+    if (my_units == 0) return;
+    auto decode = [&](int j, int& tile, int& cg) {
+        const unsigned u = blockIdx.x + (unsigned)j * (unsigned)G;
+        const unsigned n = (unsigned)n_units, qn = n >> 3, rn = n & 7, x = u & 7;
+        const unsigned logical = (x < rn ? x * (qn + 1) : rn * (qn + 1) + (x - rn) * qn) + (u >> 3);
+        const unsigned t = fastdiv(logical, FastDiv{a.fd_gy.ml, a.fd_gy.mh});
+        cg = (int)(logical - t * (unsigned)gy);
+        tile = (int)t;
+    };
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, 0x7fffffff, 0x00020000);
+    // the whole source behind one descriptor (the planner keeps it below 2^31 bytes); pixels beyond the end get an offset past num_records
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)((unsigned)total * (unsigned)a.src_cs * 2u), 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const bool tail_oob = (cib - 1) * 32 + 8 * (int)g >= a.cin4;    // last k-block: this lane's 8 channels lie beyond round_up(Cin, 8)
+    const int n_wfrag = a.n_ctiles;                                  // cout tiles; fragment (ctile, kb) at (ctile * cib + kb) KiB
+
+    // ---- pixel stream: k-block (jX, kX) of this wave's 4 pixel tiles, one chunk (KC k-blocks) ahead of the MFMAs.  A unit counts
+    // n_chunks * KC k-blocks here (those beyond cib are dummy loads), so a k-block's position in its chunk IS its ring slot: compile-time.
+    const int cibP = n_chunks * KC;
+    int jX = 0, kX = 0;
+    unsigned xvo[PT] = {kOOB, kOOB, kOOB, kOOB};
+    auto x_unit = [&]() {
+        int tile, cg;
+        decode(jX, tile, cg);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int p = tile * 256 + (wave * PT + pt) * 16 + (lane & 15);
+            xvo[pt] = p < total ? (unsigned)__mul24(p, a.src_cs) * 2u + g * 16u : kOOB;
+        }
+    };
+    f16x8 xr[KC][PT];
+    auto x_load = [&](int slot) {                               // slot: compile-time (= kX % KC by construction)
+        const bool live = jX < my_units;                        // beyond the last unit: dummy loads (every load stays unconditional)
+        if (live && kX == 0) x_unit();
+        const bool oob = !live || kX >= cib || (tail_oob && kX == cib - 1);
+        const int kb = kX < cib ? kX : cib - 1;
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+            xr[slot][pt] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(oob ? kOOB : xvo[pt]), kb * 64, 0));
+        if (live && ++kX == cibP) { kX = 0; ++jX; }
+    };
+    // ---- weight stream: chunk (jW, cW) = KC k-blocks x CT cout tiles, registers one chunk ahead of LDS, LDS one chunk ahead of the MFMAs ------
+    int jW = 0, cW = 0, wct0 = 0;
+    f16x8 pw[NWU];
+    auto w_load = [&](int u) {                                  // fragment f = 4 u + wave of the chunk: (ct, kk) = (f / KC, f % KC)
+        const int f = 4 * u + wave;
+        const int ct = f / KC, kk = f - ct * KC;
+        const int ctile = min(wct0 + ct, n_wfrag - 1), kb = min(cW * KC + kk, cib - 1);
+        pw[u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)((f < NFW && jW < my_units) ? lane16 : kOOB), (ctile * cib + kb) * 1024, 0));
+    };
+    auto w_begin = [&]() {                                      // before the loads of chunk (jW, cW)
+        if (cW == 0 && jW < my_units) { int tile, cg; decode(jW, tile, cg); wct0 = cg * CT; }
+    };
+    auto w_advance = [&]() { if (jW < my_units && ++cW == n_chunks) { cW = 0; ++jW; } };
+    auto w_commit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NWU; ++u) *(f16x8*)(lds + buf * WBUF + u * 4096 + tid * 16) = pw[u];
+    };
+
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto epilogue = [&](int j) {
+        int tile, cg;
+        decode(j, tile, cg);
+        const int ct0 = cg * CT;
+        const OutF16 o = make_out_f16(a.dst, a.dst_cs, total * a.dst_cs, a.res, a.res_cs, total * a.res_cs, 0, a.Cout, a.act, a.out_f32);
+        int pixi[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int p = tile * 256 + (wave * PT + pt) * 16 + (lane & 15);
+            pixi[pt] = p < total ? p : -1;
+        }
+        f32x4 bias4[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
+            bias4[ct] = *(const f32x4*)(a.bias + tile_cout0(ctile, lane >> 4, conv_f16_pairs(a.Cout)));
+        }
+        store_tiles_f16_v2<PT, CT>(o, acc, bias4, lane, ct0, pixi);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+
+    // prologue: weights of chunk 0 into LDS buffer 0, chunk 1 into registers; the first chunk's pixel k-blocks into the ring
+    w_begin();
+#pragma unroll
+    for (int u = 0; u < NWU; ++u) w_load(u);
+    w_advance();
+    w_commit(0);
+    w_begin();
+#pragma unroll
+    for (int u = 0; u < NWU; ++u) w_load(u);
+    w_advance();
+#pragma unroll
+    for (int d = 0; d < KC; ++d) x_load(d);
+    __syncthreads();
+    const unsigned wl = lane16;
+    int buf = 0;
+    for (int j = 0; j < my_units; ++j) {
+        for (int c = 0; c < n_chunks; ++c) {
+            const int nkk = min(KC, cib - c * KC);
+            const unsigned wb = (unsigned)buf * (unsigned)WBUF + wl;
+            // chunk (j, c) from LDS buffer `buf`.  Inside its MFMA phase: the next chunk's weights registers -> the other buffer (every wave
+            // has passed the barrier below, hence is done with that buffer), then the chunk after that into the registers.
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) {
+                if (kk < nkk) {
+                    f16x8 wf[CT];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) wf[ct] = *(const f16x8*)__builtin_assume_aligned(lds + wb + (ct * KC + kk) * 1024, 16);
+                    if (kk == 0) {
+                        w_commit(buf ^ 1);
+                        w_begin();
+#pragma unroll
+                        for (int u = 0; u < NWU; ++u) w_load(u);
+                        w_advance();
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt)
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ct], xr[kk][pt], acc[ct][pt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                x_load(kk);                                     // the k-block one chunk ahead takes this slot (a dummy beyond the unit's last one)
+            }
+            __syncthreads();                                   // everyone is done with `buf`; the other buffer's chunk is complete
+            buf ^= 1;
+        }
+        epilogue(j);
+    }
+}
+
 typedef void (*KernelFn)(ConvKArgs);
 
 }  // namespace
+
+// version-9 launch plans (pointwise): CT 3 or 6
+const void* pick_conv1x1_lw_f16(int CT) {
+    if (CT == 3) return (const void*)(KernelFn)&conv1x1_lw_f16<3>;
+    if (CT == 6) return (const void*)(KernelFn)&conv1x1_lw_f16<6>;
+    return nullptr;
+}
 
 // version-7 launch plans: CT cout tiles per block (48 / 64 / 96 couts)
 const void* pick_conv_lw_f16(int CT) {
