@@ -260,18 +260,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lw_f16(ConvKArgs a) {
     }
 }
 
-// ---- version 9 (round 4): pointwise convs in the same style ---------------------------------------------------------------------------
+// ---- version 10 (round 4): pointwise convs in the same style ---------------------------------------------------------------------------
 // What-if runs (profiles/r04_pointwise_whatif.txt) showed the half-mode 1x1 launches spending half their time in an input-staging phase nothing
 // overlaps, and a fifth waiting for weight fragments every wave fetches for itself.  Here a block = 4 waves x 64 pixels (PT = 4) = 256
-// flattened pixels x CT * 16 couts; the waves share the weights, which travel through a DOUBLE-buffered LDS region in chunks of KC = 4
-// k-blocks (registers -> LDS inside the MFMA phase of the previous chunk: one barrier per chunk, no phase of its own); a wave's own pixels
-// need no LDS at all -- their B fragments (64 contiguous bytes per pixel and k-block) stream from global memory into a register ring
-// one chunk (KC k-blocks) ahead of the MFMAs, across chunk AND unit boundaries (persistent blocks, (pixel tile, cout group) units in the XCD-aware order).
+// flattened pixels x CT * 16 couts, persistent over (pixel tile, cout group) units in the XCD-aware order.
+//   * The waves share the WEIGHTS, which travel through a double-buffered LDS region in chunks of KC = 4 k-blocks (registers -> LDS inside
+//     the MFMA phase of the previous chunk: one barrier per chunk, no phase of its own).
+//   * A wave stages ITS OWN 64 pixels two k-blocks (128 bytes per pixel = one cache line) at a time: a load instruction covers 8 pixels x one full
+//     line (version 9 of this round streamed MFMA-fragment-shaped loads -- 16 half lines per instruction, what the texture addresser is slowest
+//     at -- and lost to the older kernels on every compute-side shape: 183 vs 145 us on 1152 -> 384 at 80 x 80), the data goes registers -> a
+//     WAVE-PRIVATE 8 KiB LDS image (XOR-swizzled 16-byte slots: slot' = slot ^ ((pixel >> 1) & 7), conflict-free for ds_read_b128's lane groups
+//     and for the 8-lane write groups), and the B fragments are read from there.  Only the wave itself touches its image, so the pixel side
+//     needs no block barrier (LDS executes a wave's accesses in order); its global loads run one X-chunk ahead, across chunk and unit boundaries.
 // Same single accumulation chain over ascending k-blocks as every other half-mode plan: the same bits.
 template <int CT>
-__global__ __launch_bounds__(256, 2) void conv1x1_lw_f16(ConvKArgs a) {
+__global__ __launch_bounds__(256, 2) void conv1x1_lwx_f16(ConvKArgs a) {
     constexpr int PT = 4, KC = 4, NFW = CT * KC, NWU = (NFW + 3) / 4, WBUF = NWU * 4096;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * WBUF];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * WBUF + 4 * 8192];          // weights (two buffers) | one 8 KiB pixel image per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
     const unsigned g = (unsigned)lane >> 4;
@@ -295,31 +300,43 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lw_f16(ConvKArgs a) {
     const bool tail_oob = (cib - 1) * 32 + 8 * (int)g >= a.cin4;    // last k-block: this lane's 8 channels lie beyond round_up(Cin, 8)
     const int n_wfrag = a.n_ctiles;                                  // cout tiles; fragment (ctile, kb) at (ctile * cib + kb) KiB
 
-    // ---- pixel stream: k-block (jX, kX) of this wave's 4 pixel tiles, one chunk (KC k-blocks) ahead of the MFMAs.  A unit counts
-    // n_chunks * KC k-blocks here (those beyond cib are dummy loads), so a k-block's position in its chunk IS its ring slot: compile-time.
-    const int cibP = n_chunks * KC;
-    int jX = 0, kX = 0;
-    unsigned xvo[PT] = {kOOB, kOOB, kOOB, kOOB};
+    // ---- pixel stream: X-chunk (jX, cX) = two k-blocks (128 bytes per pixel) of this wave's 64 pixels.  A unit counts 2 * n_chunks X-chunks
+    // (those beyond cib are dummies).  Registers hold the X-chunk AFTER the one in the wave's LDS image.
+    const int nxc = 2 * n_chunks;
+    int jX = 0, cX = 0;
+    unsigned xv = kOOB; int nvi = 0;                             // lane's byte offset of (first pixel + lane / 8, slot lane % 8); load instructions whose pixel exists
+    const unsigned row8 = (unsigned)a.src_cs * 16u;              // bytes between the pixels of consecutive load instructions (8 pixels)
     auto x_unit = [&]() {
         int tile, cg;
         decode(jX, tile, cg);
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            const int p = tile * 256 + (wave * PT + pt) * 16 + (lane & 15);
-            xvo[pt] = p < total ? (unsigned)__mul24(p, a.src_cs) * 2u + g * 16u : kOOB;
-        }
+        const int p0 = tile * 256 + wave * 64 + (lane >> 3);
+        xv = (unsigned)__mul24(p0 < total ? p0 : 0, a.src_cs) * 2u + (unsigned)(lane & 7) * 16u;
+        const int left = total - p0;                             // pixels p0, p0 + 8, ...: instruction i is valid while 8 i < left
+        nvi = left <= 0 ? 0 : min(8, (left + 7) >> 3);
     };
-    f16x8 xr[KC][PT];
-    auto x_load = [&](int slot) {                               // slot: compile-time (= kX % KC by construction)
-        const bool live = jX < my_units;                        // beyond the last unit: dummy loads (every load stays unconditional)
-        if (live && kX == 0) x_unit();
-        const bool oob = !live || kX >= cib || (tail_oob && kX == cib - 1);
-        const int kb = kX < cib ? kX : cib - 1;
+    f16x8 xp[8];
+    auto x_load = [&]() {
+        const bool live = jX < my_units;
+        if (live && cX == 0) x_unit();
+        const int c0 = cX * 64 + 8 * (lane & 7);                 // this lane's first channel
+        const bool chan_ok = live && c0 < a.cin4;
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt)
-            xr[slot][pt] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(oob ? kOOB : xvo[pt]), kb * 64, 0));
-        if (live && ++kX == cibP) { kX = 0; ++jX; }
+        for (int i = 0; i < 8; ++i)
+            xp[i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((chan_ok && i < nvi) ? xv + (unsigned)i * row8 : kOOB), min(cX, (cib - 1) >> 1) * 128, 0));
+        if (live && ++cX == nxc) { cX = 0; ++jX; }
     };
+    unsigned char* ximg = lds + 2 * WBUF + wave * 8192;
+    const unsigned wv0 = (unsigned)(lane >> 3) * 128u + ((((unsigned)lane & 7u) ^ (((unsigned)lane >> 4) & 7u)) * 16u);
+    const unsigned wv1 = (unsigned)(lane >> 3) * 128u + ((((unsigned)lane & 7u) ^ ((((unsigned)lane >> 4) + 4u) & 7u)) * 16u);
+    auto x_commit = [&]() {                                     // registers -> this wave's image (in order behind the wave's own reads of the old one)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *(f16x8*)(ximg + i * 1024 + ((i & 1) ? wv1 : wv0)) = xp[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    const unsigned pr = (unsigned)lane & 15u, sz = (pr >> 1) & 7u;
+    const unsigned rv0 = pr * 128u + ((g ^ sz) * 16u), rv1 = pr * 128u + (((4u + g) ^ sz) * 16u);
+    auto xfrag = [&](int pt, int k2) -> f16x8 { return *(const f16x8*)__builtin_assume_aligned(ximg + pt * 2048 + (k2 ? rv1 : rv0), 16); };
     // ---- weight stream: chunk (jW, cW) = KC k-blocks x CT cout tiles, registers one chunk ahead of LDS, LDS one chunk ahead of the MFMAs ------
     int jW = 0, cW = 0, wct0 = 0;
     f16x8 pw[NWU];
@@ -377,8 +394,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lw_f16(ConvKArgs a) {
 #pragma unroll
     for (int u = 0; u < NWU; ++u) w_load(u);
     w_advance();
-#pragma unroll
-    for (int d = 0; d < KC; ++d) x_load(d);
+    x_load();
+    x_commit();
+    x_load();
     __syncthreads();
     const unsigned wl = lane16;
     int buf = 0;
@@ -391,9 +409,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lw_f16(ConvKArgs a) {
 #pragma unroll
             for (int kk = 0; kk < KC; ++kk) {
                 if (kk < nkk) {
-                    f16x8 wf[CT];
+                    f16x8 wf[CT], xf[PT];
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) wf[ct] = *(const f16x8*)__builtin_assume_aligned(lds + wb + (ct * KC + kk) * 1024, 16);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) xf[pt] = xfrag(pt, kk & 1);
                     if (kk == 0) {
                         w_commit(buf ^ 1);
                         w_begin();
@@ -406,10 +426,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lw_f16(ConvKArgs a) {
                     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                         for (int pt = 0; pt < PT; ++pt)
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ct], xr[kk][pt], acc[ct][pt], 0, 0, 0);
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ct], xf[pt], acc[ct][pt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                x_load(kk);                                     // the k-block one chunk ahead takes this slot (a dummy beyond the unit's last one)
+                if (kk & 1) {                                   // an X-chunk is consumed: the next one registers -> image, the one after into the registers
+                    x_commit();
+                    x_load();
+                }
             }
             __syncthreads();                                   // everyone is done with `buf`; the other buffer's chunk is complete
             buf ^= 1;
@@ -422,10 +445,10 @@ typedef void (*KernelFn)(ConvKArgs);
 
 }  // namespace
 
-// version-9 launch plans (pointwise): CT 3 or 6
-const void* pick_conv1x1_lw_f16(int CT) {
-    if (CT == 3) return (const void*)(KernelFn)&conv1x1_lw_f16<3>;
-    if (CT == 6) return (const void*)(KernelFn)&conv1x1_lw_f16<6>;
+// version-10 launch plans (pointwise): CT 3 or 6
+const void* pick_conv1x1_lwx_f16(int CT) {
+    if (CT == 3) return (const void*)(KernelFn)&conv1x1_lwx_f16<3>;
+    if (CT == 6) return (const void*)(KernelFn)&conv1x1_lwx_f16<6>;
     return nullptr;
 }
 

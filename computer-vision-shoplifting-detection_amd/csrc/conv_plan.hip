@@ -205,18 +205,18 @@ std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int ci
         }
     }
     if (half && ks == 1 && stride == 1 && !need_v4) {
-        // v9 (conv_f16_lw.hip: conv1x1_lw_f16): 256 flattened pixels x CT * 16 couts per block, the block's weights through a double-buffered LDS
-        // region, each wave's pixel fragments streamed from global memory a chunk ahead, persistent blocks.  Not with the fused upsample.
-        static const int use_v9 = env_int("MI355_CONV_V9", 1);
+        // v10 (conv_f16_lw.hip: conv1x1_lwx_f16): 256 flattened pixels x CT * 16 couts per block, the block's weights through a double-buffered LDS
+        // region, each wave's pixels staged in full cache lines through a wave-private LDS image, persistent blocks.  Not with the fused upsample.
+        static const int use_v10 = env_int("MI355_CONV_V10", 1);
         const int cts[2] = {6, 3};                              // 64- and 32-cout blocks never won a shape (tools/r04_call31.sh)
-        for (int ci = 0; ci < 2 && use_v9; ++ci) {
+        for (int ci = 0; ci < 2 && use_v10; ++ci) {
             const int CT = cts[ci];
             if (CT > n_ctiles) continue;
             const int nblk = (n_ctiles + CT - 1) / CT;
             if (nblk * CT >= 2 * n_ctiles && nblk * CT > CT) continue;
-            Plan p9{CT, 4, 256, 1, 16, 0, 0.0, 9, 0, 4};
-            p9.cost = (double)nblk * CT / n_ctiles * (1.0 + 0.05 * (nblk - 1)) * 0.7;
-            out.push_back(p9);
+            Plan p10{CT, 4, 256, 1, 16, 0, 0.0, 10, 0, 4};
+            p10.cost = (double)nblk * CT / n_ctiles * (1.0 + 0.05 * (nblk - 1)) * 0.7;
+            out.push_back(p10);
         }
     }
     if (ks == 1 && have_zero_page) {        // streaming pointwise kernel (needs the zero page as well): CT x PT register tiles
@@ -309,7 +309,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     } else {
         a.Hin = c.Hin; a.Win = c.Win; a.Hout = c.Hout; a.Wout = c.Wout;
     }
-    KernelFn fn = half ? (p.version == 7 ? (KernelFn)pick_conv_lw_f16(p.CT) : p.version == 9 ? (KernelFn)pick_conv1x1_lw_f16(p.CT) : p.version == 4 ? (KernelFn)pick_conv_pipe_f16(p.CT, p.WP, (c.Cin + 1) / 2 <= p.ck, p.ck > 64)
+    KernelFn fn = half ? (p.version == 7 ? (KernelFn)pick_conv_lw_f16(p.CT) : p.version == 10 ? (KernelFn)pick_conv1x1_lwx_f16(p.CT) : p.version == 4 ? (KernelFn)pick_conv_pipe_f16(p.CT, p.WP, (c.Cin + 1) / 2 <= p.ck, p.ck > 64)
                           : p.f2 ? (KernelFn)pick_conv_fused_f16(c.stride, p.CT, p.WP, p.PT)
                                  : (p.version == 1 && (p.PT == 1 || p.PT == 2)) ? (KernelFn)pick_conv_small_f16(c.k, c.stride, p.CT, p.WP, p.PT)
                                  : (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.version == 3 ? p.buf_floats : p.PT))
@@ -361,10 +361,10 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     }
     out->grid_y = (unsigned)((a.n_ctiles + p.CT * WC * a.cgroups - 1) / (p.CT * WC * a.cgroups));
     unsigned v7_gy = 1;
-    if (p.version == 7 || p.version == 9) {
+    if (p.version == 7 || p.version == 10) {
         // persistent: as many blocks as stay resident (two per CU), each walks units blockIdx.x, + gridDim.x, ...; unit = (tile, cout group)
         if (p.version == 7 && c.pad != 1) return "conv: the LDS-weights kernel needs pad 1";
-        if (p.version == 9 && c.src2) return "conv: the LDS-weights pointwise kernel has no fused upsample";
+        if (p.version == 10 && c.src2) return "conv: the LDS-weights pointwise kernel has no fused upsample";
         v7_gy = (unsigned)((a.n_ctiles + p.CT - 1) / p.CT);
         a.cgroups = (int)v7_gy;
         int per_cu = 0;
@@ -377,7 +377,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     }
     if ((unsigned long long)out->grid_x * out->grid_y >= (1u << 24)) return "conv: more than 2^24 blocks in one launch";
     a.fd_tx = make_fastdiv((unsigned)std::max(1, a.tiles_x)); a.fd_ty = make_fastdiv((unsigned)std::max(1, a.tiles_y));
-    a.fd_gy = make_fastdiv(std::max(1u, (p.version == 7 || p.version == 9) ? v7_gy : out->grid_y));
+    a.fd_gy = make_fastdiv(std::max(1u, (p.version == 7 || p.version == 10) ? v7_gy : out->grid_y));
     if (!half && (p.version == 1 || p.f2)) {
         // conv_igemm_f32 addresses one image of each slice through a buffer descriptor with 32-bit byte offsets (a pointwise
         // launch sees the flattened batch as one image), and lanes / pad channels whose store must be DROPPED are given the
@@ -397,7 +397,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
         a.st_nseg = row_slots >= 256 ? (row_slots + 255) / 256 : 1;
         a.inv_row_slots = 1.0f / (float)row_slots;
     }
-    if (half && (p.version == 1 || p.version == 7 || p.version == 9 || p.f2)) {
+    if (half && (p.version == 1 || p.version == 7 || p.version == 10 || p.f2)) {
         // conv_igemm_f16 (round 3): source / destination / residual images behind buffer descriptors with 32-bit byte offsets and
         // the drop marker 0x80000000 -- every image must stay below 2^31 bytes, and a source row below 2^24 bytes (24-bit multiply)
         const long long lim = 1ll << 31;

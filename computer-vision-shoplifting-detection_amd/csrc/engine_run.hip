@@ -84,7 +84,7 @@ int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, const Ge
                 // v1: one block per tile; v4 (persistent): keep the planned grid unless fewer tiles exist
                 // v7 (persistent over (tile, cout group) units): likewise
                 l.grid_x = l.version == 4 ? std::min(l.grid_x, (unsigned)l.a.n_tiles_total)
-                         : (l.version == 7 || l.version == 9) ? std::min(l.grid_x, (unsigned)l.a.n_tiles_total * (unsigned)l.a.cgroups) : (unsigned)l.a.n_tiles_total;
+                         : (l.version == 7 || l.version == 10) ? std::min(l.grid_x, (unsigned)l.a.n_tiles_total * (unsigned)l.a.cgroups) : (unsigned)l.a.n_tiles_total;
             }
             if (pf.begin(K_CONV)) return fail(MI355_EHIP, "event");
             KCHK(run_conv(l, st));

@@ -61,12 +61,12 @@ def test_half_3x3_stride_1_convs_are_offered_the_lds_weights_kernels_and_nothing
     assert 7 not in ops.plan_versions(16, 4, 4, 192, 192, 3, half=True, src_cs=192, dst_cs=192)    # maps smaller than half a tile
 
 
-def test_half_pointwise_convs_are_offered_the_lds_weights_streaming_kernel():
-    """Round 4: launch-plan version 9 (csrc/conv_f16_lw.hip: conv1x1_lw_f16 -- shared weights through double-buffered LDS, each wave's pixel
-    fragments streamed a chunk ahead, persistent blocks of 256 pixels x 96 / 48 couts) for half=True pointwise convs; never for fp32, 3x3 convs
-    or fewer than three cout tiles."""
+def test_half_pointwise_convs_are_offered_the_lds_weights_kernel():
+    """Round 4: launch-plan version 10 (csrc/conv_f16_lw.hip: conv1x1_lwx_f16 -- shared weights through double-buffered LDS, each wave's pixels staged
+    in full cache lines through a wave-private LDS image, persistent blocks of 256 pixels x 96 / 48 couts) for half=True pointwise convs; never for
+    fp32, 3x3 convs or fewer than three cout tiles."""
     v = ops.plan_versions(16, 160, 160, 576, 192, 1, half=True, src_cs=576, dst_cs=192)
-    assert v.count(9) == 2 and {1, 4} <= set(v)
-    assert 9 not in ops.plan_versions(16, 160, 160, 576, 192, 1)
-    assert 9 not in ops.plan_versions(16, 160, 160, 192, 192, 3, half=True, src_cs=192, dst_cs=192)
-    assert 9 not in ops.plan_versions(16, 40, 40, 64, 32, 1, half=True, src_cs=64, dst_cs=32)
+    assert v.count(10) == 2 and {1, 4} <= set(v)
+    assert 10 not in ops.plan_versions(16, 160, 160, 576, 192, 1)
+    assert 10 not in ops.plan_versions(16, 160, 160, 192, 192, 3, half=True, src_cs=192, dst_cs=192)
+    assert 10 not in ops.plan_versions(16, 40, 40, 64, 32, 1, half=True, src_cs=64, dst_cs=32)
