@@ -299,12 +299,26 @@ def measure_config(model_name: str, size: int, batch: int, half: bool, steps: in
     achieved = conv_flops_per_frame(model_name, size) * batch / (conv_ms * 1e-3) / 1e12
     peak = F16_PEAK_TFLOPS if half else FP32_PEAK_TFLOPS
     plan = model.plan_info()
+    # HBM traffic per conv launch of BASELINE config 5 at batch 16: quoted from its PMC passes (profiles/) when -- and only when -- they ran the
+    # same launch plans as this process (as the headline's roofline.traffic)
+    traffic = traffic_source = None
+    if half and model_name == "yolov8m" and size == 1280 and batch == 16 and not fast_act:
+        tpath = os.path.join(ROOT, "profiles", "r04_cfg5_conv_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("plan_hash") == plan["plan_hash"]:
+                traffic = tj["hbm_bytes_per_launch_avg"]
+                traffic_source = f"profiles/r04_cfg5_conv_traffic.json (separate rocprofv3 --pmc passes of this workload, same plan_hash {plan['plan_hash']})"
+            else:
+                traffic_source = f"profiles/r04_cfg5_conv_traffic.json not quoted: collected on plan_hash {tj.get('plan_hash')}, this run has {plan['plan_hash']}"
     out = {"workload": f"{model_name} {size}x{size} batch {batch}" + (" half=True" if half else "") + (" fast_act=1 (tolerance mode, opt-in)" if fast_act else ""),
            "dtype": "f16" if half else "f32",
            "value": round(batch * steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
            "roofline": {"achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                         **roofline_fractions(model_name, size, batch, half, conv_ms),
-                        "launches_per_step": launches, "plan_hash": plan["plan_hash"], "plan_source": plan["plan_source"]},
+                        "launches_per_step": launches, "plan_hash": plan["plan_hash"], "plan_source": plan["plan_source"],
+                        **({"traffic": traffic, "traffic_source": traffic_source} if traffic_source else {})},
            "activation_bytes": plan["activation_bytes"]}
     if fast_act:
         # parity of the tolerance mode, measured here (no CPU timing belongs to it): rows against the torch-CPU oracle and both against
@@ -568,7 +582,7 @@ def main() -> None:
                    "parallelism": f"frame-sharded dp{world}", "collectives_backend": backend, "ranks": world,
                    "collective_world_size": comm_world,
                    "collectives_per_step": 0 if world == 1 else 2},
-        "roofline": {"bound": "mfma", "kernel": ("conv_igemm_f16 + conv3x3_lw_f16 + conv1x1_pipe_f16" if args.half else "conv_igemm_f32 + conv1x1_pipe_f32 + conv1x1_stream_f32") + " (every conv launch of a step)",
+        "roofline": {"bound": "mfma", "kernel": ("conv_igemm_f16 + conv3x3_lw_f16 + conv1x1_lwx_f16 + conv1x1_pipe_f16" if args.half else "conv_igemm_f32 + conv1x1_pipe_f32 + conv1x1_stream_f32") + " (every conv launch of a step)",
                      "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
                      **{k: v for k, v in roofline_fractions(args.model, args.size, B, args.half, conv_ms).items() if k != "bound"},
