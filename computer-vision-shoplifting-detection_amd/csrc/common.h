@@ -54,7 +54,7 @@ const void* pick_conv_kernel_f16(int ks, int stride, int CT, int WP, int version
 const void* pick_conv_pipe_f16(int CT, int WP, bool single, bool nkk8);
 const void* pick_conv_fused_f16(int stride, int CT, int WP, int PT);       // conv_f16_fused.hip; PT 0 (= 4) or 8
 const void* pick_conv_small_f16(int ks, int stride, int CT, int WP, int PT);   // conv_f16_small.hip; PT 1 or 2, CT 1 or 2
-const void* pick_conv1x1_lwx_f16(int CT);                                     // conv_f16_lw.hip (version 10: pointwise, shared weights through LDS, pixels staged in full lines through wave-private LDS); CT 3 or 6
+const void* pick_conv1x1_lwx_f16(int CT, bool up);                                     // conv_f16_lw.hip (version 10: pointwise, shared weights through LDS, pixels staged in full lines through wave-private LDS); CT 3 or 6
 const void* pick_conv_lw_f16(int CT);                                         // conv_f16_lw.hip (version 7: weights in LDS, persistent); CT 3, 4 or 6
 // Division of a block-uniform number by a launch constant on the SCALAR unit (tile decomposition of the conv kernels; the
 // compiler's own lowering of an integer division runs on the vector ALU, which the fp32 matrix instructions share):

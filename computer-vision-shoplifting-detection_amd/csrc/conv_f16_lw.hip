@@ -273,7 +273,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lw_f16(ConvKArgs a) {
 //     and for the 8-lane write groups), and the B fragments are read from there.  Only the wave itself touches its image, so the pixel side
 //     needs no block barrier (LDS executes a wave's accesses in order); its global loads run one X-chunk ahead, across chunk and unit boundaries.
 // Same single accumulation chain over ascending k-blocks as every other half-mode plan: the same bits.
-template <int CT>
+// UP: the nearest-2x upsample fused into the read side, as conv1x1_pipe_f16 / conv1x1_stream_up_f32 have it -- the X-chunks of the first a.up_c input
+// channels (whole 64-channel chunks) are staged from the half-resolution tensor a.src2 at (y >> 1, x >> 1); fd_tx / fd_ty divide by up_W / up_W * up_H.
+template <int CT, bool UP = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_lwx_f16(ConvKArgs a) {
     constexpr int PT = 4, KC = 4, NFW = CT * KC, NWU = (NFW + 3) / 4, WBUF = NWU * 4096;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * WBUF + 4 * 8192];          // weights (two buffers) | one 8 KiB pixel image per wave
@@ -306,6 +308,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lwx_f16(ConvKArgs a) {
     int jX = 0, cX = 0;
     unsigned xv = kOOB; int nvi = 0;                             // lane's byte offset of (first pixel + lane / 8, slot lane % 8); load instructions whose pixel exists
     const unsigned row8 = (unsigned)a.src_cs * 16u;              // bytes between the pixels of consecutive load instructions (8 pixels)
+    unsigned xv2[UP ? 8 : 1];                                    // UP: byte offset of instruction i's pixel in the half-resolution tensor
+    const __amdgpu_buffer_rsrc_t x2rs = UP ? __builtin_amdgcn_make_buffer_rsrc((void*)a.src2, 0, (int)((unsigned)(total >> 2) * (unsigned)a.src2_cs * 2u), 0x00020000) : xrs;
     auto x_unit = [&]() {
         int tile, cg;
         decode(jX, tile, cg);
@@ -313,6 +317,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lwx_f16(ConvKArgs a) {
         xv = (unsigned)__mul24(p0 < total ? p0 : 0, a.src_cs) * 2u + (unsigned)(lane & 7) * 16u;
         const int left = total - p0;                             // pixels p0, p0 + 8, ...: instruction i is valid while 8 i < left
         nvi = left <= 0 ? 0 : min(8, (left + 7) >> 3);
+        if constexpr (UP) {
+            const unsigned W2 = (unsigned)a.up_W >> 1, H2 = (unsigned)a.up_H >> 1, HW = (unsigned)(a.up_W * a.up_H);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned p = (unsigned)min(p0 + 8 * i, total - 1);
+                const unsigned b = fastdiv(p, FastDiv{a.fd_ty.ml, a.fd_ty.mh}), r = p - b * HW;
+                const unsigned y = fastdiv(r, FastDiv{a.fd_tx.ml, a.fd_tx.mh}), x = r - y * (unsigned)a.up_W;
+                xv2[i] = ((b * H2 + (y >> 1)) * W2 + (x >> 1)) * (unsigned)a.src2_cs * 2u + (unsigned)(lane & 7) * 16u;
+            }
+        }
     };
     f16x8 xp[8];
     auto x_load = [&]() {
@@ -320,9 +334,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lwx_f16(ConvKArgs a) {
         if (live && cX == 0) x_unit();
         const int c0 = cX * 64 + 8 * (lane & 7);                 // this lane's first channel
         const bool chan_ok = live && c0 < a.cin4;
+        const int so = min(cX, (cib - 1) >> 1) * 128;
+        if (UP && cX * 64 < a.up_c) {                            // wave-uniform: this X-chunk lives in the half-resolution tensor
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            xp[i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((chan_ok && i < nvi) ? xv + (unsigned)i * row8 : kOOB), min(cX, (cib - 1) >> 1) * 128, 0));
+            for (int i = 0; i < 8; ++i)
+                xp[i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(x2rs, (int)((chan_ok && i < nvi) ? xv2[UP ? i : 0] : kOOB), so, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                xp[i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((chan_ok && i < nvi) ? xv + (unsigned)i * row8 : kOOB), so, 0));
+        }
         if (live && ++cX == nxc) { cX = 0; ++jX; }
     };
     unsigned char* ximg = lds + 2 * WBUF + wave * 8192;
@@ -445,8 +466,13 @@ typedef void (*KernelFn)(ConvKArgs);
 
 }  // namespace
 
-// version-10 launch plans (pointwise): CT 3 or 6
-const void* pick_conv1x1_lwx_f16(int CT) {
+// version-10 launch plans (pointwise): CT 3 or 6; up: with the nearest-2x upsample fused into the read side
+const void* pick_conv1x1_lwx_f16(int CT, bool up) {
+    if (up) {
+        if (CT == 3) return (const void*)(KernelFn)&conv1x1_lwx_f16<3, true>;
+        if (CT == 6) return (const void*)(KernelFn)&conv1x1_lwx_f16<6, true>;
+        return nullptr;
+    }
     if (CT == 3) return (const void*)(KernelFn)&conv1x1_lwx_f16<3>;
     if (CT == 6) return (const void*)(KernelFn)&conv1x1_lwx_f16<6>;
     return nullptr;

@@ -204,7 +204,7 @@ std::vector<Plan> enumerate_plans(int H, int W, int images, int n_ctiles, int ci
             out.push_back(p7);
         }
     }
-    if (half && ks == 1 && stride == 1 && !need_v4) {
+    if (half && ks == 1 && stride == 1) {                        // also with the fused upsample (need_v4: the conv reads through an upsample)
         // v10 (conv_f16_lw.hip: conv1x1_lwx_f16): 256 flattened pixels x CT * 16 couts per block, the block's weights through a double-buffered LDS
         // region, each wave's pixels staged in full cache lines through a wave-private LDS image, persistent blocks.  Not with the fused upsample.
         static const int use_v10 = env_int("MI355_CONV_V10", 1);
@@ -309,7 +309,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     } else {
         a.Hin = c.Hin; a.Win = c.Win; a.Hout = c.Hout; a.Wout = c.Wout;
     }
-    KernelFn fn = half ? (p.version == 7 ? (KernelFn)pick_conv_lw_f16(p.CT) : p.version == 10 ? (KernelFn)pick_conv1x1_lwx_f16(p.CT) : p.version == 4 ? (KernelFn)pick_conv_pipe_f16(p.CT, p.WP, (c.Cin + 1) / 2 <= p.ck, p.ck > 64)
+    KernelFn fn = half ? (p.version == 7 ? (KernelFn)pick_conv_lw_f16(p.CT) : p.version == 10 ? (KernelFn)pick_conv1x1_lwx_f16(p.CT, c.src2 != nullptr) : p.version == 4 ? (KernelFn)pick_conv_pipe_f16(p.CT, p.WP, (c.Cin + 1) / 2 <= p.ck, p.ck > 64)
                           : p.f2 ? (KernelFn)pick_conv_fused_f16(c.stride, p.CT, p.WP, p.PT)
                                  : (p.version == 1 && (p.PT == 1 || p.PT == 2)) ? (KernelFn)pick_conv_small_f16(c.k, c.stride, p.CT, p.WP, p.PT)
                                  : (KernelFn)pick_conv_kernel_f16(c.k, c.stride, p.CT, p.WP, p.version, p.version == 3 ? p.buf_floats : p.PT))
@@ -364,7 +364,9 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     if (p.version == 7 || p.version == 10) {
         // persistent: as many blocks as stay resident (two per CU), each walks units blockIdx.x, + gridDim.x, ...; unit = (tile, cout group)
         if (p.version == 7 && c.pad != 1) return "conv: the LDS-weights kernel needs pad 1";
-        if (p.version == 10 && c.src2) return "conv: the LDS-weights pointwise kernel has no fused upsample";
+        if (p.version == 10 && c.src2) {      // upsample fused into the read side: whole 64-channel X-chunks from the half-resolution tensor
+            if ((c.up_c & 63) || (long long)(a.Wout / 4) * c.src2_cs * 2 >= (1ll << 31)) return "conv: the LDS-weights pointwise kernel cannot fuse this upsample";
+        }
         v7_gy = (unsigned)((a.n_ctiles + p.CT - 1) / p.CT);
         a.cgroups = (int)v7_gy;
         int per_cu = 0;
@@ -397,6 +399,7 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
         a.st_nseg = row_slots >= 256 ? (row_slots + 255) / 256 : 1;
         a.inv_row_slots = 1.0f / (float)row_slots;
     }
+    if (p.version == 10 && c.src2) { a.fd_tx = make_fastdiv((unsigned)c.Win); a.fd_ty = make_fastdiv((unsigned)(c.Win * c.Hin)); }
     if (half && (p.version == 1 || p.version == 7 || p.version == 10 || p.f2)) {
         // conv_igemm_f16 (round 3): source / destination / residual images behind buffer descriptors with 32-bit byte offsets and
         // the drop marker 0x80000000 -- every image must stay below 2^31 bytes, and a source row below 2^24 bytes (24-bit multiply)
@@ -446,7 +449,7 @@ const char* plan_conv_candidates(const ConvArgs& c, std::vector<ConvLaunch>* out
     if (plans.empty()) return "conv: no launch plan fits in LDS";
     const char* last_err = nullptr;
     for (const Plan& p : plans) {
-        if (c.src2 && p.version != 4 && !(p.version == 3 && !half)) continue;       // upsample-on-read: the pipelined kernels and the fp32 streaming kernel
+        if (c.src2 && p.version != 4 && !(p.version == 3 && !half) && !(p.version == 10 && half)) continue;       // upsample-on-read: the pipelined kernels and the fp32 streaming kernel
         ConvLaunch l{};
         if (const char* e = build_launch(c, p, &l)) {   // e.g. the fused form exists for fewer wave shapes than the plain one
             last_err = e;

@@ -112,12 +112,13 @@ int mi355_op_conv2d_f16(int device_id, const float* x, int n, int h, int w, int 
 // Pointwise conv over cat(upsample2x(x_half), x_skip) with the upsample fused into the conv's read side (fp32): the parity hook of the
 // neck's Upsample -> Concat -> C2f.cv1 chain as the engine runs it (the up channels of the concat buffer are never written: they
 // are poisoned here, so a plan that reads them shows).
-int mi355_op_conv1x1_upcat(int device_id, const float* x_half, const float* x_skip, int n, int h, int w, int up_c, int skip_c,
-                           const float* w_oihw, const float* bias, int cout, int silu, float* y, int plan_index, int* n_plans) {
+static int op_conv1x1_upcat_impl(int device_id, const float* x_half, const float* x_skip, int n, int h, int w, int up_c, int skip_c,
+                                 const float* w_oihw, const float* bias, int cout, int silu, float* y, int plan_index, int* n_plans, bool half) {
     if (!x_half || !x_skip || !w_oihw || !bias || !y || n <= 0 || h <= 0 || w <= 0 || up_c <= 0 || skip_c <= 0 || cout <= 0) return fail(MI355_EINVAL, "bad argument");
     if ((h & 1) || (w & 1) || (up_c & 15)) return fail(MI355_EINVAL, "h and w must be even and up_c a multiple of 16");
     HIPCHK(hipSetDevice(device_id));
-    const int cin = up_c + skip_c, cs_in = round_up(cin, 4), cs_h = round_up(up_c, 4), cs_out = round_up(cout, 4);
+    const int es = half ? 2 : 4, al = 16 / es;
+    const int cin = up_c + skip_c, cs_in = round_up(cin, al), cs_h = round_up(up_c, al), cs_out = round_up(cout, al);
     const size_t np = (size_t)n * h * w, nph = np / 4;
     std::vector<float> xin(np * cs_in, 0.f), xh(nph * cs_h, 0.f), yout(np * cs_out, 0.f);
     const float poison = std::numeric_limits<float>::quiet_NaN();
@@ -128,17 +129,32 @@ int mi355_op_conv1x1_upcat(int device_id, const float* x_half, const float* x_sk
     for (size_t p = 0; p < nph; ++p) std::memcpy(&xh[p * cs_h], x_half + p * up_c, (size_t)up_c * 4);
     DevMem dm; float *d_x, *d_h, *d_y, *d_w, *d_b, *d_z;
     HIPCHK(dm.alloc(&d_z, 256)); HIPCHK(hipMemset(d_z, 0, 256));
-    HIPCHK(dm.alloc(&d_x, xin.size() * 4)); HIPCHK(hipMemcpy(d_x, xin.data(), xin.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(dm.alloc(&d_h, xh.size() * 4)); HIPCHK(hipMemcpy(d_h, xh.data(), xh.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(dm.alloc(&d_y, yout.size() * 4)); HIPCHK(hipMemset(d_y, 0, yout.size() * 4));
-    std::vector<float> pk(packed_weight_floats(cout, cin, 1)), bp(round_up(cout, 16), 0.f);
-    pack_conv_weights(w_oihw, cout, cin, 1, pk.data());
+    auto upload = [&](float** dptr, const std::vector<float>& v) -> int {
+        HIPCHK(dm.alloc(dptr, v.size() * es));
+        if (!half) { HIPCHK(hipMemcpy(*dptr, v.data(), v.size() * 4, hipMemcpyHostToDevice)); return MI355_OK; }
+        std::vector<uint16_t> hb(v.size());
+        floats_to_halfs(v.data(), hb.data(), v.size());
+        HIPCHK(hipMemcpy(*dptr, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+        return MI355_OK;
+    };
+    int rc = upload(&d_x, xin); if (rc) return rc;
+    rc = upload(&d_h, xh); if (rc) return rc;
+    HIPCHK(dm.alloc(&d_y, yout.size() * es)); HIPCHK(hipMemset(d_y, 0, yout.size() * es));
+    std::vector<float> bp(round_up(cout, 16), 0.f);
     std::memcpy(bp.data(), bias, (size_t)cout * 4);
-    HIPCHK(dm.alloc(&d_w, pk.size() * 4)); HIPCHK(hipMemcpy(d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+    if (half) {
+        std::vector<uint16_t> pk(packed_weight_halfs(cout, cin, 1));
+        pack_conv_weights_f16(w_oihw, cout, cin, 1, pk.data());
+        HIPCHK(dm.alloc(&d_w, pk.size() * 2)); HIPCHK(hipMemcpy(d_w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> pk(packed_weight_floats(cout, cin, 1));
+        pack_conv_weights(w_oihw, cout, cin, 1, pk.data());
+        HIPCHK(dm.alloc(&d_w, pk.size() * 4)); HIPCHK(hipMemcpy(d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+    }
     HIPCHK(dm.alloc(&d_b, bp.size() * 4)); HIPCHK(hipMemcpy(d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
     ConvArgs a{};
     a.src = d_x; a.src_cs = cs_in; a.dst = d_y; a.dst_cs = cs_out; a.wpk = d_w; a.bias = d_b; a.zeros = d_z;
-    a.src2 = d_h; a.src2_cs = cs_h; a.up_c = up_c;
+    a.src2 = d_h; a.src2_cs = cs_h; a.up_c = up_c; a.dtype = half ? 1 : 0;
     a.B = n; a.Hin = h; a.Win = w; a.Hout = h; a.Wout = w; a.Cin = cin; a.Cout = cout; a.k = 1; a.stride = 1; a.pad = 0; a.act = silu ? 1 : 0;
     std::vector<ConvLaunch> cands;
     KCHK(plan_conv_candidates(a, &cands));
@@ -146,9 +162,25 @@ int mi355_op_conv1x1_upcat(int device_id, const float* x_half, const float* x_sk
     if (n_plans) *n_plans = (int)cands.size();
     KCHK(run_conv(l, nullptr));
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(yout.data(), d_y, yout.size() * 4, hipMemcpyDeviceToHost));
+    if (!half) {
+        HIPCHK(hipMemcpy(yout.data(), d_y, yout.size() * 4, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<uint16_t> hb(yout.size());
+        HIPCHK(hipMemcpy(hb.data(), d_y, hb.size() * 2, hipMemcpyDeviceToHost));
+        halfs_to_floats(hb.data(), yout.data(), hb.size());
+    }
     for (size_t p = 0; p < np; ++p) std::memcpy(y + p * cout, &yout[p * cs_out], (size_t)cout * 4);
     return MI355_OK;
+}
+
+int mi355_op_conv1x1_upcat(int device_id, const float* x_half, const float* x_skip, int n, int h, int w, int up_c, int skip_c,
+                           const float* w_oihw, const float* bias, int cout, int silu, float* y, int plan_index, int* n_plans) {
+    return op_conv1x1_upcat_impl(device_id, x_half, x_skip, n, h, w, up_c, skip_c, w_oihw, bias, cout, silu, y, plan_index, n_plans, false);
+}
+
+int mi355_op_conv1x1_upcat_f16(int device_id, const float* x_half, const float* x_skip, int n, int h, int w, int up_c, int skip_c,
+                               const float* w_oihw, const float* bias, int cout, int silu, float* y, int plan_index, int* n_plans) {
+    return op_conv1x1_upcat_impl(device_id, x_half, x_skip, n, h, w, up_c, skip_c, w_oihw, bias, cout, silu, y, plan_index, n_plans, true);
 }
 
 // Conv3x3 (+bias+SiLU) -> Conv1x1 (+bias, optional SiLU) as ONE fused launch (conv_igemm_f32 / _f16 <..., F2 = true>): the parity

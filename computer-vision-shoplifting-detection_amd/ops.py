@@ -48,9 +48,9 @@ def conv2d(x_nhwc: np.ndarray, w_oihw: np.ndarray, bias: np.ndarray, stride: int
 
 
 def conv1x1_upcat(x_half: np.ndarray, x_skip: np.ndarray, w_oihw: np.ndarray, bias: np.ndarray, silu: bool = True, device: int = 0,
-                  plan: int = 0, return_n_plans: bool = False):
+                  plan: int = 0, return_n_plans: bool = False, half: bool = False):
     """Pointwise conv over cat(upsample2x(x_half), x_skip) with the upsample fused into the read side (fp32):
-    x_half [N,H/2,W/2,Cu], x_skip [N,H,W,Cs], w [Cout,Cu+Cs,1,1] -> [N,H,W,Cout]."""
+    x_half [N,H/2,W/2,Cu], x_skip [N,H,W,Cs], w [Cout,Cu+Cs,1,1] -> [N,H,W,Cout].  ``half``: the half=True kernels."""
     xh, xs, w, b = _f32(x_half), _f32(x_skip), _f32(w_oihw), _f32(bias)
     n, h, wd, cs = xs.shape
     cu, cout = xh.shape[3], w.shape[0]
@@ -58,7 +58,8 @@ def conv1x1_upcat(x_half: np.ndarray, x_skip: np.ndarray, w_oihw: np.ndarray, bi
         raise ValueError("shape mismatch")
     y = np.empty((n, h, wd, cout), dtype=np.float32)
     npl = C.c_int(0)
-    _lib.check(_lib.lib().mi355_op_conv1x1_upcat(device, xh.ctypes.data, xs.ctypes.data, n, h, wd, cu, cs, w.ctypes.data, b.ctypes.data,
+    fn = _lib.lib().mi355_op_conv1x1_upcat_f16 if half else _lib.lib().mi355_op_conv1x1_upcat
+    _lib.check(fn(device, xh.ctypes.data, xs.ctypes.data, n, h, wd, cu, cs, w.ctypes.data, b.ctypes.data,
                                                  cout, int(silu), y.ctypes.data, int(plan), C.byref(npl)))
     return (y, npl.value) if return_n_plans else y
 

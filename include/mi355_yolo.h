@@ -202,6 +202,10 @@ int  mi355_op_conv2d_f16(int device_id, const float* x, int n, int h, int w, int
  * concatenation, bit for bit, for every plan_index. */
 int  mi355_op_conv1x1_upcat(int device_id, const float* x_half, const float* x_skip, int n, int h, int w, int up_c, int skip_c,
                             const float* w_oihw, const float* bias, int cout, int silu, float* y, int plan_index, int* n_plans);
+/* The same on the half=True path (operands rounded to fp16 on the way in, fp32 accumulation, y rounded to fp16 once): must equal
+ * mi355_op_conv2d_f16 on the materialised concatenation, bit for bit, for every plan_index. */
+int  mi355_op_conv1x1_upcat_f16(int device_id, const float* x_half, const float* x_skip, int n, int h, int w, int up_c, int skip_c,
+                                const float* w_oihw, const float* bias, int cout, int silu, float* y, int plan_index, int* n_plans);
 /* Conv3x3 (stride 1|2, pad 1) + bias + SiLU -> Conv1x1 + bias (+SiLU if silu2) run as ONE fused launch, the way the engine runs
  * a 3x3 conv whose only reader is a pointwise conv (the first conv's output never leaves the chip).  x[n][h][w][cin],
  * w1[c1][cin][3][3], b1[c1], w2[c2][c1][1][1], b2[c2] -> y[n][h/stride][w/stride][c2]; must equal the two convs run separately,

@@ -323,3 +323,24 @@ def test_reference_call_sites_with_half(v8n_pose):
     assert seen >= 1
     r = m(frames[0], conf=0.1)[0]
     assert r.keypoints.data.shape[1:] == (17, 3) and len(r.keypoints) == len(r.boxes)
+
+
+@pytest.mark.parametrize("n,h,w,cu,cs,cout", [(2, 40, 40, 576, 384, 384), (1, 80, 80, 384, 192, 192), (2, 20, 24, 64, 32, 96), (1, 24, 20, 128, 72, 80)])
+def test_half_pointwise_conv_reading_through_the_upsample_every_plan(n, h, w, cu, cs, cout):
+    """Round 4: the neck's Upsample -> Concat -> C2f.cv1 in half mode with the upsample fused into the conv's read side -- the pipelined kernel and
+    the LDS-weights kernel (conv1x1_lwx_f16<.., UP>: whole 64-channel X-chunks staged from the half-resolution map).  Every plan must give
+    the bits of the plain half-mode conv on the materialised concatenation (same fp16-rounded operands, same accumulation order); the concat
+    buffer's up channels are poisoned with NaN by the op entry."""
+    from cvsd_amd import ops
+    rng = np.random.default_rng(cu + cs + cout + h)
+    xh = rng.standard_normal((n, h // 2, w // 2, cu), dtype=np.float32)
+    xs = rng.standard_normal((n, h, w, cs), dtype=np.float32)
+    wt = (rng.standard_normal((cout, cu + cs, 1, 1)) / np.sqrt(cu + cs)).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    cat = np.concatenate([xh.repeat(2, axis=1).repeat(2, axis=2), xs], axis=3)
+    ref = ops.conv2d(cat, wt, b, stride=1, silu=True, half=True)
+    y, n_plans = ops.conv1x1_upcat(xh, xs, wt, b, silu=True, half=True, return_n_plans=True)
+    np.testing.assert_array_equal(y, ref)
+    assert n_plans >= 2
+    for plan in range(1, n_plans):
+        np.testing.assert_array_equal(ops.conv1x1_upcat(xh, xs, wt, b, silu=True, half=True, plan=plan), ref, err_msg=f"plan {plan} of {n_plans}")
