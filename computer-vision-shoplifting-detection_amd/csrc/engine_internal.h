@@ -53,7 +53,7 @@ struct FileConv { char name[64]; uint32_t cin, cout, k, s, pad, act; uint64_t w_
 struct FileLevel { uint32_t buf, box_off, cls_off, kpt_off, stride; };
 #pragma pack(pop)
 
-struct DevConv { float* wpk = nullptr; float* bias = nullptr; float* w_raw = nullptr; };
+struct DevConv { float* wpk = nullptr; float* bias = nullptr; float* w_raw = nullptr; void* w_frag = nullptr; };   // w_frag: stem3_weight_frags (half k3 stems)
 
 // LetterBox geometry (data/augment.py:LetterBox, auto=True, scaleup=True, center=True, stride 32) and the
 // scale-back constants of utils/ops.py:scale_boxes / scale_coords, in the same double arithmetic as Python.

@@ -24,7 +24,7 @@ mi355_yolo::~mi355_yolo() {
     if (stream) (void)hipStreamSynchronize(stream);      // an asynchronous call may still be running on the buffers freed below
     for (auto st : aux) if (st) (void)hipStreamSynchronize(st);
     free_shape();
-    for (auto& c : dconv) { if (c.wpk) (void)hipFree(c.wpk); if (c.bias) (void)hipFree(c.bias); if (c.w_raw) (void)hipFree(c.w_raw); }
+    for (auto& c : dconv) { if (c.wpk) (void)hipFree(c.wpk); if (c.bias) (void)hipFree(c.bias); if (c.w_raw) (void)hipFree(c.w_raw); if (c.w_frag) (void)hipFree(c.w_frag); }
     if (lut) (void)hipFree(lut);
     if (zeros) (void)hipFree(zeros);
     if (d_in) (void)hipFree(d_in);
@@ -124,6 +124,12 @@ int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
         if (c.cin == 3) {                      // stem: raw OIHW, read by stem_mfma_u8
             HIPCHK(hipMalloc(&d.w_raw, wn * 4));
             HIPCHK(hipMemcpy(d.w_raw, w, wn * 4, hipMemcpyHostToDevice));
+            if (h->half && c.k == 3) {         // A fragments of stem3s2_u8_h
+                std::vector<uint16_t> fr;
+                stem3_weight_frags(w, (int)c.cout, fr);
+                HIPCHK(hipMalloc(&d.w_frag, fr.size() * 2));
+                HIPCHK(hipMemcpy(d.w_frag, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+            }
         } else if (h->half) {
             const size_t pn = packed_weight_halfs(c.cout, c.cin, c.k);
             std::vector<uint16_t> th(pn);

@@ -443,32 +443,56 @@ int mi355_plan_query(int n, int h, int w, int cin, int cout, int k, int stride, 
     return MI355_OK;
 }
 
-int mi355_op_stem(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias, int cout,
-                  int k, int stride, float* y) {
+static int op_stem_impl(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias, int cout,
+                        int k, int stride, bool half, int variant, void* y) {
     if (!bgr || !w_oihw || !bias || !y || n <= 0 || h <= 0 || w <= 0 || cout <= 0) return fail(MI355_EINVAL, "bad argument");
     if ((k != 3 && k != 6) || (h % stride) || (w % stride)) return fail(MI355_EINVAL, "k/stride not supported");
     HIPCHK(hipSetDevice(device_id));
     const int ho = h / stride, wo = w / stride, cs = round_up(cout, 4);
+    const size_t es = half ? 2 : 4;
     DevMem dm; uint8_t* d_img; float *d_y, *d_w, *d_b, *d_l;
     const size_t ib = (size_t)n * h * w * 3, yn = (size_t)n * ho * wo * cs;
     float lut[256];
     for (int i = 0; i < 256; ++i) lut[i] = (float)i / 255.0f;
-    HIPCHK(dm.alloc(&d_img, ib)); HIPCHK(dm.alloc(&d_y, yn * 4)); HIPCHK(dm.alloc(&d_w, (size_t)cout * 3 * k * k * 4));
-    HIPCHK(dm.alloc(&d_b, (size_t)cout * 4)); HIPCHK(dm.alloc(&d_l, sizeof(lut)));
+    HIPCHK(dm.alloc(&d_img, ib)); HIPCHK(dm.alloc(&d_y, yn * es)); HIPCHK(dm.alloc(&d_w, (size_t)cout * 3 * k * k * 4));
+    const int bn = round_up(cout, 16);                               // the engine's bias arrays are padded the same way
+    HIPCHK(dm.alloc(&d_b, (size_t)bn * 4)); HIPCHK(dm.alloc(&d_l, sizeof(lut)));
     HIPCHK(hipMemcpy(d_img, bgr, ib, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_w, w_oihw, (size_t)cout * 3 * k * k * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d_b, 0, (size_t)bn * 4));
     HIPCHK(hipMemcpy(d_b, bias, (size_t)cout * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_l, lut, sizeof(lut), hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(d_y, 0, yn * 4));
+    HIPCHK(hipMemset(d_y, 0, yn * es));
     StemArgs s{};
+    if (half && k == 3) {
+        std::vector<uint16_t> fr;
+        stem3_weight_frags(w_oihw, cout, fr);
+        uint16_t* d_f;
+        HIPCHK(dm.alloc(&d_f, fr.size() * 2));
+        HIPCHK(hipMemcpy(d_f, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+        s.wfrag = d_f;
+    }
     s.img = d_img; s.dst = d_y; s.dst_cs = cs; s.w = d_w; s.bias = d_b; s.lut = d_l;
     s.B = n; s.H = h; s.W = w; s.Hout = ho; s.Wout = wo; s.Cout = cout; s.k = k; s.stride = stride; s.pad = (k == 6 ? 2 : k / 2);
+    s.out_half = half ? 1 : 0; s.variant = variant;
     KCHK(launch_stem(s, nullptr));
     HIPCHK(hipDeviceSynchronize());
-    std::vector<float> yo(yn);
-    HIPCHK(hipMemcpy(yo.data(), d_y, yn * 4, hipMemcpyDeviceToHost));
-    for (size_t p = 0; p < (size_t)n * ho * wo; ++p) std::memcpy(y + p * cout, &yo[p * cs], (size_t)cout * 4);
+    std::vector<uint8_t> yo(yn * es);
+    HIPCHK(hipMemcpy(yo.data(), d_y, yn * es, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < (size_t)n * ho * wo; ++p) std::memcpy((uint8_t*)y + p * cout * es, &yo[p * cs * es], (size_t)cout * es);
     return MI355_OK;
+}
+
+int mi355_op_stem(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias, int cout,
+                  int k, int stride, float* y) {
+    return op_stem_impl(device_id, bgr, n, h, w, w_oihw, bias, cout, k, stride, false, 0, y);
+}
+
+int mi355_op_stem_f16(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias, int cout,
+                      int k, int stride, int variant, uint16_t* y) {
+    if (variant < 0 || (variant & 255) > 2 || (variant >> 8) > 31) return fail(MI355_EINVAL, "variant must be 0 (the launcher's choice), 1 (general) or 2 (k3 s2)");
+    if ((variant & 255) == 2 && (k != 3 || stride != 2 || (w & 3))) return fail(MI355_EINVAL, "variant 2 is the k 3, stride 2 kernel for widths that are multiples of 4");
+    return op_stem_impl(device_id, bgr, n, h, w, w_oihw, bias, cout, k, stride, true, variant, y);
 }
 
 int mi355_op_nms(int device_id, const float* pred, int n, int nc, int extra, int anchors, float conf, float iou,

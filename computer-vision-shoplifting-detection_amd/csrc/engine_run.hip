@@ -52,7 +52,7 @@ int launch_net(mi355_yolo* h, Prof& pf, const uint8_t* stem_in, int nb, const Ge
             const FileConv& c = h->convs[o.conv];
             StemArgs s{};
             s.img = stem_in; s.dst = dst; s.dst_cs = h->dbuf_cs[o.dst_buf];
-            s.w = h->dconv[o.conv].w_raw; s.bias = h->dconv[o.conv].bias; s.lut = h->lut;
+            s.w = h->dconv[o.conv].w_raw; s.bias = h->dconv[o.conv].bias; s.lut = h->lut; s.wfrag = h->dconv[o.conv].w_frag;
             s.B = nb; s.H = g.Hl; s.W = g.Wl; s.Hout = g.Hl / sd_out; s.Wout = g.Wl / sd_out;
             s.Cout = c.cout; s.k = c.k; s.stride = c.s; s.pad = c.pad;
             s.out_half = h->dbuf_es[o.dst_buf] == 2; s.fast_act = h->fast_act ? 1 : 0;

@@ -3,6 +3,7 @@
 #include "common.h"
 #include "detmath.h"
 #include <cstdlib>
+#include <vector>
 
 #pragma clang fp contract(off)
 
@@ -12,6 +13,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef MI355_STEM_DIAG
+#define MI355_STEM_DIAG 0      // 1: stem3s2_u8_h reads what-if bits from StemArgs::variant >> 8 (A/B builds only)
+#endif
 #ifndef MI355_STEM_EXP
 #define MI355_STEM_EXP 0       // what-if builds only (tools/ab_build.sh): 1 no SiLU, 2 no input conversion, 4 no stores, 8 no MFMAs
 #endif
@@ -313,6 +317,161 @@ __global__ __launch_bounds__(256) void stem_mfma_u8_h(StemArgs a) {
     }
 }
 
+// The half stem for the shape every Ultralytics v8 model has (k 3, stride 2, pad 1).  The general form above is bound by its
+// memory INSTRUCTIONS, not by arithmetic or bytes (what-if runs, tools/stem_whatif.py on config 5's 16 frames of 1280 x 1280: 389 us
+// whole, 180 us without the stores, 238 us without the input and weight loads, 77 us with neither); this one issues a third of them:
+//  * the input tile is fetched as ALIGNED DWORDS: with W a multiple of 4 a tile row starts at byte 96 tx - 3 of its image row, so the
+//    26 dwords from byte 96 tx - 4 cover it and each lies wholly inside or wholly outside the image -- 4 loads per thread instead of
+//    14 byte loads, no edge cases.  Byte c of the tile row is stored as the fp16 value (half)(b * (1/255.f)) at half index c + 1 of the
+//    LDS row ((half)(b * (1/255.f)) == (half)(b / 255.f) for all 256 bytes: tests/test_half_stem_table.py), one ds_write_b64 per load;
+//  * the A operand comes from a table the host prepares once per model (stem3_weight_frags below): three 16-byte loads per lane
+//    instead of 24 dword loads and their index arithmetic;
+//  * k is PERMUTED inside the one MFMA (K = 27 <= 32; the sum of 27 exact products defines no order, the general form's does not
+//    either): pixel lx's nine values of kernel row kh sit at half indices 6 lx + 1 .. 6 lx + 9 of tile row 2 ly + kh, so lane group
+//    g < 3 takes the four aligned dwords 6 lx .. 6 lx + 7 of row kh = g (the neighbour's last byte meets a zero weight, then values
+//    0..6) and group 3 takes the dword 6 lx + 8, 6 lx + 9 (values 7, 8) of each of the three rows -- no per-value gather, no packing;
+//  * the couts are PERMUTED over the MFMA rows so that a lane's 4 CT results are 4 CT consecutive channels of its pixel
+//    (row 4 g + j of cout tile ct is channel 4 CT g + 4 ct + j): a wave's stores of one pixel row are one contiguous run of
+//    16 pixels x Cout halfs, written with 16-byte stores.
+// LDS rows are 108 halfs (216 B): 8-byte aligned for the staging writes, and the four lane groups' dword reads fall in distinct banks.
+constexpr int STEM3_ROW = 108;
+
+// [ct][lane][8] fp16 bit patterns: the A fragments of stem3s2_u8_h.  Byte channel cb (0=B,1=G,2=R) feeds model channel 2-cb (im[..., ::-1]).
+void stem3_weight_frags(const float* w_oihw, int cout, std::vector<uint16_t>& out) {
+    const int CT = (cout + 15) / 16;
+    std::vector<float> f((size_t)CT * 64 * 8, 0.f);
+    for (int ct = 0; ct < CT; ++ct)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int g = lane >> 4, r16 = lane & 15;
+            const int co = 4 * CT * (r16 >> 2) + 4 * ct + (r16 & 3);
+            if (co >= cout) continue;
+            for (int s = 0; s < 8; ++s) {
+                int kh, r;
+                if (g < 3) { kh = g; r = s - 1; } else { kh = s >> 1; r = 7 + (s & 1); }
+                if (r < 0 || kh > 2) continue;
+                const int kw = r / 3, cb = r % 3;
+                f[((size_t)ct * 64 + lane) * 8 + s] = w_oihw[((size_t)co * 3 + (2 - cb)) * 9 + kh * 3 + kw];
+            }
+        }
+    out.resize(f.size());
+    floats_to_halfs(f.data(), out.data(), f.size());
+}
+
+template <int CT>
+__global__ __launch_bounds__(256) void stem3s2_u8_h(StemArgs a) {
+    constexpr int TIN = 2 * (STEM_TO - 1) + 3, ROW = STEM3_ROW, PT = 4, NDW = 26, NIT = TIN * NDW;
+    __shared__ __attribute__((aligned(16))) _Float16 tin[TIN * ROW];
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const int tiles_x = (a.Wout + STEM_TO - 1) / STEM_TO, tiles_y = (a.Hout + STEM_TO - 1) / STEM_TO;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int oy0 = ty * STEM_TO, ox0 = tx * STEM_TO;
+    const int iy0 = oy0 * 2 - 1, gd0 = (ox0 * 2 - 1) * 3 - 1;  // first tile row; byte (in its image row) of the row's first dword: 96 tx - 4
+    const uint8_t* img = a.img + (size_t)b * a.H * a.W * 3;
+    const int wrow = a.W * 3;
+#if MI355_STEM_DIAG
+    const int diag = a.variant >> 8;                            // what-if runs (tools/stem_whatif.py): 1 no SiLU, 2 no input loads, 4 no stores, 16 no weights
+#else
+    constexpr int diag = 0;
+#endif
+    // ---- input tile: 4 dwords per thread, all loads before the first conversion; outside the image -> 0 ----
+    unsigned dw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int it = tid + 256 * u;
+        const int iy = it / NDW, m = it - iy * NDW;
+        const int gy = iy0 + iy, gd = gd0 + 4 * m;
+        const bool in = it < NIT && (unsigned)gy < (unsigned)a.H && gd >= 0 && gd + 4 <= wrow;
+        const unsigned v = (diag & 2) ? (unsigned)it * 0x01010101u : *(const unsigned*)(img + (in ? gy * wrow + gd : 0));
+        dw[u] = in ? v : 0u;
+    }
+    f16x8 wa[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        if (diag & 16) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wa[ct][j] = (_Float16)(0.01f * (float)(lane + j));
+        } else {
+            wa[ct] = *(const f16x8*)((const uint16_t*)a.wfrag + ((size_t)ct * 64 + lane) * 8);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int it = tid + 256 * u;
+        const int iy = it / NDW, m = it - iy * NDW;
+        f16x2 lo, hi;
+        lo[0] = (_Float16)((float)(dw[u] & 255u) * (1.0f / 255.0f));
+        lo[1] = (_Float16)((float)((dw[u] >> 8) & 255u) * (1.0f / 255.0f));
+        hi[0] = (_Float16)((float)((dw[u] >> 16) & 255u) * (1.0f / 255.0f));
+        hi[1] = (_Float16)((float)(dw[u] >> 24) * (1.0f / 255.0f));
+        u32x2 pk;
+        pk[0] = __builtin_bit_cast(unsigned, lo); pk[1] = __builtin_bit_cast(unsigned, hi);
+        if (it < NIT) *(u32x2*)(tin + iy * ROW + 4 * m) = pk;
+    }
+    __syncthreads();
+    int off[4];                                                 // byte offsets of the lane's four dwords from its pixel's base
+#pragma unroll
+    for (int d = 0; d < 4; ++d) off[d] = g < 3 ? g * (ROW * 2) + 4 * d : (d < 3 ? d : 0) * (ROW * 2) + 16;
+    const char* tb = (const char*)tin;
+    // lane holds channels 4 CT g + 4 ct + j of pixel (row 4*wave + pt, column lane & 15)
+    const int c0 = 4 * CT * g;
+    float bs[CT][4];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bs[ct][j] = a.bias[c0 + 4 * ct + j];          // the bias array is padded to 16 CT floats
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int base = ((wave * PT + pt) * 2 * ROW + (lane & 15) * 6) * 2;
+        u32x4 xv;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) xv[d] = *(const unsigned*)(tb + base + off[d]);
+        const f16x8 xb = __builtin_bit_cast(f16x8, xv);
+        f32x4 acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ct], xb, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const int oy = oy0 + wave * PT + pt, ox = ox0 + (lane & 15);
+        if (oy >= a.Hout || ox >= a.Wout || c0 >= a.Cout) continue;
+        if ((diag & 4) && acc[0][0] != 12345.678f) continue;
+        const size_t po = ((size_t)b * a.Hout + oy) * a.Wout + ox;
+        _Float16* dh = (_Float16*)a.dst + po * a.dst_cs + c0;
+        _Float16 o[4 * CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = acc[ct][j] + bs[ct][j];
+                o[4 * ct + j] = (_Float16)((diag & 1) ? v : silu_fast(v));
+            }
+        if (c0 + 4 * CT <= a.Cout) {
+            typedef _Float16 f16x8a __attribute__((ext_vector_type(8), aligned(8)));
+#pragma unroll
+            for (int q = 0; q + 1 < CT; q += 2) {
+                f16x8a v8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v8[j] = o[4 * q + j];
+                *(f16x8a*)(dh + 4 * q) = v8;
+            }
+            if (CT & 1) {
+                f16x4 v4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v4[j] = o[4 * (CT - 1) + j];
+                *(f16x4*)(dh + 4 * (CT - 1)) = v4;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4 * CT; ++j)
+                if (c0 + j < a.Cout) dh[j] = o[j];
+        }
+    }
+}
+
 template <int KS>
 static bool launch_stem_mfma(const StemArgs& a, unsigned grid, hipStream_t st) {
     const int tin = (STEM_TO - 1) * a.stride + KS;
@@ -320,6 +479,18 @@ static bool launch_stem_mfma(const StemArgs& a, unsigned grid, hipStream_t st) {
     if (lds > 64 * 1024) return false;
     const int ct = (a.Cout + 15) / 16;
     static const bool h_stem = !getenv("MI355_STEM_F16") || atoi(getenv("MI355_STEM_F16")) != 0;
+    static const bool h_lean = !getenv("MI355_STEM_LEAN") || atoi(getenv("MI355_STEM_LEAN")) != 0;
+    if (a.out_half && KS == 3 && a.stride == 2 && a.pad == 1 && a.wfrag && !(a.W & 3) && !((uintptr_t)a.img & 3) && (a.variant & 255) != 1 &&
+        (h_lean || (a.variant & 255) == 2)) {
+        switch (ct) {
+            case 1: hipLaunchKernelGGL((stem3s2_u8_h<1>), dim3(grid), dim3(256), 0, st, a); return true;
+            case 2: hipLaunchKernelGGL((stem3s2_u8_h<2>), dim3(grid), dim3(256), 0, st, a); return true;
+            case 3: hipLaunchKernelGGL((stem3s2_u8_h<3>), dim3(grid), dim3(256), 0, st, a); return true;
+            case 4: hipLaunchKernelGGL((stem3s2_u8_h<4>), dim3(grid), dim3(256), 0, st, a); return true;
+            case 5: hipLaunchKernelGGL((stem3s2_u8_h<5>), dim3(grid), dim3(256), 0, st, a); return true;
+            default: return false;
+        }
+    }
     if (a.out_half && h_stem) {                      // half=True: fp16 operands (the fp32 kernel's LDS size covers the fp16 tile)
         switch (ct) {
             case 1: hipLaunchKernelGGL((stem_mfma_u8_h<KS, 1>), dim3(grid), dim3(256), lds, st, a); return true;

@@ -85,12 +85,20 @@ def conv2d_fused(x_nhwc: np.ndarray, w1: np.ndarray, b1: np.ndarray, w2: np.ndar
     return (y, npl.value) if return_n_plans else y
 
 
-def stem(bgr_u8: np.ndarray, w_oihw: np.ndarray, bias: np.ndarray, stride: int = 2, device: int = 0) -> np.ndarray:
-    """uint8 BGR frames [N,H,W,3] -> /255, RGB -> conv kxk + bias + SiLU -> [N,H/s,W/s,Cout]."""
+def stem(bgr_u8: np.ndarray, w_oihw: np.ndarray, bias: np.ndarray, stride: int = 2, device: int = 0, half: bool = False,
+         variant: int = 0) -> np.ndarray:
+    """uint8 BGR frames [N,H,W,3] -> /255, RGB -> conv kxk + bias + SiLU -> [N,H/s,W/s,Cout].
+    half=True: the half predictor's arithmetic (input, weights and output rounded to fp16, fp32 accumulation), float16 result;
+    variant 0 = the kernel the engine launches, 1 = the general kernel, 2 = the k 3 / stride 2 kernel."""
     img = np.ascontiguousarray(bgr_u8, dtype=np.uint8)
     w, b = _f32(w_oihw), _f32(bias)
     n, h, wd, _ = img.shape
     cout, _, k, _ = w.shape
+    if half:
+        yh = np.empty((n, h // stride, wd // stride, cout), dtype=np.float16)
+        _lib.check(_lib.lib().mi355_op_stem_f16(device, img.ctypes.data, n, h, wd, w.ctypes.data, b.ctypes.data, cout, k,
+                                                stride, int(variant), yh.ctypes.data))
+        return yh
     y = np.empty((n, h // stride, wd // stride, cout), dtype=np.float32)
     _lib.check(_lib.lib().mi355_op_stem(device, img.ctypes.data, n, h, wd, w.ctypes.data, b.ctypes.data, cout, k,
                                         stride, y.ctypes.data))

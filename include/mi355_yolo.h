@@ -343,6 +343,10 @@ int  mi355_gmc_track_state(const mi355_gmc* g, int* oh, int* ow, int* n_pts, uin
 /* The u8 stem: letterboxed BGR frames -> (x/255, RGB) -> conv k x k stride s (pad k/2, or 2 for k=6) + bias + SiLU. */
 int  mi355_op_stem(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias,
                    int cout, int k, int stride, float* y);
+/* The half=True form of the same op (input, weights and output rounded to fp16 as the half predictor does, fp32 accumulation); y holds
+ * fp16 bit patterns.  variant: 0 = the kernel the engine launches, 1 = the general kernel, 2 = the k 3 / stride 2 kernel. */
+int  mi355_op_stem_f16(int device_id, const uint8_t* bgr, int n, int h, int w, const float* w_oihw, const float* bias,
+                       int cout, int k, int stride, int variant, uint16_t* y);
 /* data/augment.py:LetterBox on uint8 BGR frames (cv2.resize INTER_LINEAR fixed-point + 114 border).
  * out must hold n * out_h * out_w * 3 bytes where (out_h,out_w) = mi355_letterbox_shape(). */
 int  mi355_letterbox_shape(int height, int width, int imgsz, int* out_h, int* out_w);

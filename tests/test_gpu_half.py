@@ -344,3 +344,52 @@ def test_half_pointwise_conv_reading_through_the_upsample_every_plan(n, h, w, cu
     assert n_plans >= 2
     for plan in range(1, n_plans):
         np.testing.assert_array_equal(ops.conv1x1_upcat(xh, xs, wt, b, silu=True, half=True, plan=plan), ref, err_msg=f"plan {plan} of {n_plans}")
+
+
+STEM_CASES = [
+    # n, h, w, cout, k
+    (2, 64, 96, 16, 3),           # yolov8n
+    (1, 96, 64, 48, 3),           # yolov8m (config 5)
+    (1, 34, 36, 32, 3),           # ragged tiles: 17 x 18 output pixels
+    (1, 34, 38, 32, 3),           # a width that is not a multiple of 4: general kernel only
+    (1, 32, 32, 80, 3),           # yolov8x
+    (1, 32, 64, 18, 3),           # cout that is not a multiple of four: the element-wise tail of the store
+    (1, 64, 64, 48, 6),           # yolov5u's 6 x 6 stem: general kernel only
+]
+
+
+@pytest.mark.parametrize("case", STEM_CASES)
+def test_half_stem_both_kernels_against_float64(case):
+    """The stem under half=True (engine/predictor.py:preprocess with half -> model.0): (u8 / 255) and the weights rounded to fp16,
+    products exact, fp32 sum, one rounding on the store.  The k 3 / stride 2 kernel sums the 27 products in a different order
+    from the general one (misc_kernels.hip:stem3s2_u8_h); both must sit within half an fp16 ulp plus fp32 accumulation noise of
+    a float64 evaluation of the same rounded operands."""
+    import torch
+    import torch.nn.functional as F
+    from cvsd_amd import ops
+    n, h, w, cout, k = case
+    rng = np.random.default_rng(sum(case))
+    img = rng.integers(0, 256, size=(n, h, w, 3), dtype=np.uint8)
+    img[0, :3, :5] = 0
+    img[0, -2:, -7:] = 255
+    wt = (rng.standard_normal((cout, 3, k, k)) * 0.4).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.2).astype(np.float32)
+    x = _f16(img[..., ::-1].astype(np.float32) / np.float32(255.0))
+    y = F.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2), torch.from_numpy(_f16(wt)).double(), torch.from_numpy(b).double(),
+                 stride=2, padding=2 if k == 6 else 1)
+    ref = (y * torch.sigmoid(y)).permute(0, 2, 3, 1).numpy()
+    mag = np.abs(ref) + 1e-3
+    got = {}
+    lean = k == 3 and w % 4 == 0
+    for variant in ((0, 1, 2) if lean else (0, 1)):
+        out = ops.stem(img, wt, b, stride=2, half=True, variant=variant)
+        assert out.dtype == np.float16 and out.shape == ref.shape
+        err = np.abs(out.astype(np.float64) - ref) / mag
+        assert err.max() < F16_EPS * 1.02 + 2e-5, f"variant {variant}: {err.max():.3e}"
+        got[variant] = out
+    if lean:
+        # the two kernels agree except where the different summation order moves a value across an fp16 rounding boundary
+        d = got[1].astype(np.float32) != got[2].astype(np.float32)
+        assert d.mean() < 2e-3
+    with pytest.raises(Exception):
+        ops.stem(img, wt, b, stride=2, half=True, variant=3 if lean else 2)

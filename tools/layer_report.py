@@ -17,7 +17,7 @@ prog = engine_program(*parse_model_name(model))     # the program the engine run
 sched_log = sys.argv[6] if len(sys.argv) > 6 else None      # bench log with the engine's "[sched] pos op stream launched" lines
 rows = [r for r in csv.DictReader(open(path)) if "mi355" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Dispatch_Id"]))              # host enqueue order (kernels of different streams overlap in time)
-kind = {OP_STEM: "stem_", OP_CONV: "conv", OP_UPSAMPLE: "upsample2x", OP_SPPF_POOL: "sppf_pools"}
+kind = {OP_STEM: "stem", OP_CONV: "conv", OP_UPSAMPLE: "upsample2x", OP_SPPF_POOL: "sppf_pools"}
 tail = ["decode_kernel"]          # ... followed by the NMS launches (nms_sort + nms_greedy, or the multi-launch sort of big maps), folded into one row
 orders = [list(range(len(prog.ops)))]                       # program order (profiling passes) ...
 launched = {i: True for i in range(len(prog.ops))}

@@ -9,7 +9,7 @@ dur, cnt = collections.defaultdict(float), collections.defaultdict(int)
 for i in range(1, 5):
     f = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{i}", "*", "*counter_collection.csv"))[0]
     rows = list(csv.DictReader(open(f)))
-    start = max(int(r["Dispatch_Id"]) for r in rows if "stem_mfma" in r["Kernel_Name"])      # last pass of the run
+    start = max(int(r["Dispatch_Id"]) for r in rows if "::stem" in r["Kernel_Name"])      # last pass of the run
     seen = set()
     for r in rows:
         if int(r["Dispatch_Id"]) < start:

@@ -8,7 +8,7 @@ rows = sorted(csv.DictReader(open(kt)), key=lambda r: int(r["Start_Timestamp"]))
 GMC = ("gray_resize", "min_eig", "corner_mask", "pyr_down", "lk_kernel")
 is_gmc = lambda n: any(g in n for g in GMC)
 K = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Queue_Id"]) for r in rows]
-stems = [i for i, k in enumerate(K) if "stem_mfma" in k[2]]
+stems = [i for i, k in enumerate(K) if "::stem" in k[2]]
 out = []
 for a, b in zip(stems[20:-3], stems[21:-2]):
     q = K[a][3]
