@@ -54,8 +54,8 @@ __device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
 // member of a grouped launch reads its block from the kernarg segment on demand: conv_f32_group.hip)
 template <int STRIDE, int PT, int CT, int WP, class KA>
 __device__ __forceinline__ void conv_epilogue(const KA& a, f32x4 (&acc)[CT][PT], const f32x4 (&bias4)[CT], int lane, int wp,
-                                              int ct0, int b, int oy0, int ox0, int npix) {
-    if (a.act == 2) {
+                                              int ct0, int b, int oy0, int ox0, int npix, int act) {
+    if (act == 2) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -64,7 +64,7 @@ __device__ __forceinline__ void conv_epilogue(const KA& a, f32x4 (&acc)[CT][PT],
                 v[0] = silu_fast_f(v[0]); v[1] = silu_fast_f(v[1]); v[2] = silu_fast_f(v[2]); v[3] = silu_fast_f(v[3]);
                 acc[ct][pt] = v;
             }
-    } else if (a.act) {
+    } else if (act) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -158,7 +158,17 @@ __device__ __forceinline__ void store_tile(f32x4 v, const float* bias, int act, 
                                  // tools/ab_build.sh: 1 -> 4 costs a 12-byte spill outside the loop, buys 2-3 % on the stride-2 layers, 0-1 % elsewhere)
 #endif
 template <int KS, int STRIDE, int PT, int CT, int WP, bool F2 = false, class KA = ConvKArgs>
-__device__ __forceinline__ void conv_igemm_f32_body(const KA& a, float* lds, const BlockId& bid) {
+__device__ __forceinline__ void conv_igemm_f32_body(const KA& a_in, float* lds, const BlockId& bid) {
+    // What-if diagnostics, built only with -DMI355_F32_DIAG=1 (tools/ab_build.sh) and selected by MI355_F32_EXP (conv_plan.hip puts it in the high
+    // bits of `act`): 1 = the halo tile is read from the zero page (the loads stay, their HBM traffic goes), 4 = every store gets an offset past the
+    // descriptor's range (dropped)
+    const KA& a = a_in;
+#ifdef MI355_F32_DIAG
+    const int diag = a.act >> 8, act1 = a.act & 255;
+#else
+    constexpr int diag = 0;
+    const int act1 = a.act;
+#endif
     constexpr int WC = 4 / WP;
     constexpr int TAPS = KS * KS;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -237,7 +247,7 @@ __device__ __forceinline__ void conv_igemm_f32_body(const KA& a, float* lds, con
                         const int iy = (int)(((float)pix + 0.5f) * a.inv_TWin);
                         const int ix = pix - iy * a.TWin;
                         const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + 4 * q;
-                        const bool inb = idx < total_f4 && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && c < a.cin4;
+                        const bool inb = idx < total_f4 && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && c < a.cin4 && !(diag & 1);
                         const float* g = inb ? srcb + ((size_t)gy * a.Win + gx) * a.src_cs + c : a.zeros;
                         v[u] = *(const f32x4*)g;
                     }
@@ -351,7 +361,7 @@ __device__ __forceinline__ void conv_igemm_f32_body(const KA& a, float* lds, con
         }
 
         if constexpr (!F2) {
-            conv_epilogue<STRIDE, PT, CT, WP, KA>(a, tot, bias4, lane, wp, ct0, b, oy0, ox0, npix);
+            conv_epilogue<STRIDE, PT, CT, WP, KA>(a, tot, bias4, lane, wp, ct0, b, oy0, ox0, (diag & 4) ? 0 : npix, act1);
         } else {
             // first conv's output (bias + activation applied: the value the unfused launch would have stored) -> LDS image
             // [pixel][channel] with pixel stride ldp2, behind the halo tile; padded cout tiles (all-zero weights and bias)
@@ -377,7 +387,7 @@ __device__ __forceinline__ void conv_igemm_f32_body(const KA& a, float* lds, con
                 for (int ct = 0; ct < CT; ++ct) {
                     if (ct0 + ct >= a.n_ctiles) continue;
                     f32x4 v = tot[ct][pt] + bias4[ct];
-                    v = act4(v, a.act);
+                    v = act4(v, act1);
                     if (a.res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs1, (int)rvo, (ct0 + ct) * 64, 0));
                     *(f32x4*)(y1 + ((wp * PT + pt) * 16 + (lane & 15)) * a.ldp2 + (ct0 + ct) * 16 + (lane >> 4) * 4) = v;
                 }
@@ -411,7 +421,7 @@ __device__ __forceinline__ void conv_igemm_f32_body(const KA& a, float* lds, con
             const int ly = (int)(((float)pp + 0.5f) * a.inv_TW);
             const int lx = pp - __mul24(ly, a.TW);
             const int oy = oy0 + ly, ox = ox0 + lx;
-            const bool ok = (p < npix) && (oy < a.Hout) && (ox < a.Wout);
+            const bool ok = (p < npix) && (oy < a.Hout) && (ox < a.Wout) && !(diag & 4);
             const int pix = __mul24(oy, a.Wout) + ox;
             dvo[pt] = ok ? (unsigned)__mul24(pix, a.dst2_cs) * 4u + (unsigned)(lane >> 4) * 16u : 0x80000000u;
             lvo[pt] = ok ? (unsigned)__mul24(pix, a.lead_cs) * 4u + (unsigned)(lane >> 4) * 16u : 0x80000000u;

@@ -298,6 +298,9 @@ static const char* build_launch(const ConvArgs& c, const Plan& p, ConvLaunch* ou
     a.src = c.src; a.dst = c.dst; a.res = c.res; a.wpk = c.wpk; a.bias = c.bias;
     a.src_cs = c.src_cs; a.dst_cs = c.dst_cs; a.res_cs = c.res_cs;
     a.Cin = c.Cin; a.Cout = c.Cout; a.pad = c.pad; a.act = c.act;
+#ifdef MI355_F32_DIAG
+    if (c.dtype != 1 && p.version == 1) { static const int ex32 = env_int("MI355_F32_EXP", 0); a.act |= ex32 << 8; }
+#endif
     const bool half = c.dtype == 1;
     a.cib = half ? (c.Cin + 31) / 32 : (c.Cin + 15) / 16; a.n_ctiles = (c.Cout + 15) / 16;
     a.cin4 = half ? round_up(c.Cin, 8) : round_up(c.Cin, 4);       // channels covered by whole 16-byte vectors
