@@ -127,9 +127,10 @@ struct StemArgs {
     int out_half = 0;                  // 1: dst holds fp16 (dst_cs counts halfs); arithmetic stays fp32, one rounding on the store
     int fast_act = 0;                  // fp32 output: 1 = SiLU on v_exp / v_rcp (opts.fast_act) instead of the canonical form
     int variant = 0;                   // half output: 0 = the launcher's choice, 1 = the general kernel, 2 = the k3 s2 kernel (tests)
-    const void* wfrag = nullptr;       // device: stem3_weight_frags() of w (k 3 half stems; without it the general kernel runs)
+    const void* wfrag = nullptr;       // device: stem3_weight_frags() (half output) / stem3_weight_frags_f32() of w (k 3 stems; without it the general kernel runs)
 };
 void stem3_weight_frags(const float* w_oihw, int cout, std::vector<uint16_t>& out);   // [ceil(cout/16)][64][8] fp16 bit patterns
+void stem3_weight_frags_f32(const float* w_oihw, int cout, std::vector<float>& out);   // [ceil(cout/16)][7][64] floats (fp32 k3 stems)
 const char* launch_stem(const StemArgs& a, hipStream_t st);
 const char* launch_upsample2x(const float* src, int src_cs, float* dst, int dst_cs, int B, int H, int W, int C,
                               hipStream_t st);

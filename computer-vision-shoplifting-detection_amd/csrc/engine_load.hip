@@ -129,6 +129,11 @@ int parse_blob(mi355_yolo* h, const uint8_t* blob, size_t n) {
                 stem3_weight_frags(w, (int)c.cout, fr);
                 HIPCHK(hipMalloc(&d.w_frag, fr.size() * 2));
                 HIPCHK(hipMemcpy(d.w_frag, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+            } else if (c.k == 3) {             // ... of stem3s2_u8_f32
+                std::vector<float> fr;
+                stem3_weight_frags_f32(w, (int)c.cout, fr);
+                HIPCHK(hipMalloc(&d.w_frag, fr.size() * 4));
+                HIPCHK(hipMemcpy(d.w_frag, fr.data(), fr.size() * 4, hipMemcpyHostToDevice));
             }
         } else if (h->half) {
             const size_t pn = packed_weight_halfs(c.cout, c.cin, c.k);

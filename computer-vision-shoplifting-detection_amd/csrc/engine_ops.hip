@@ -471,6 +471,13 @@ static int op_stem_impl(int device_id, const uint8_t* bgr, int n, int h, int w, 
         HIPCHK(dm.alloc(&d_f, fr.size() * 2));
         HIPCHK(hipMemcpy(d_f, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
         s.wfrag = d_f;
+    } else if (k == 3) {
+        std::vector<float> fr;
+        stem3_weight_frags_f32(w_oihw, cout, fr);
+        float* d_f;
+        HIPCHK(dm.alloc(&d_f, fr.size() * 4));
+        HIPCHK(hipMemcpy(d_f, fr.data(), fr.size() * 4, hipMemcpyHostToDevice));
+        s.wfrag = d_f;
     }
     s.img = d_img; s.dst = d_y; s.dst_cs = cs; s.w = d_w; s.bias = d_b; s.lut = d_l;
     s.B = n; s.H = h; s.W = w; s.Hout = ho; s.Wout = wo; s.Cout = cout; s.k = k; s.stride = stride; s.pad = (k == 6 ? 2 : k / 2);

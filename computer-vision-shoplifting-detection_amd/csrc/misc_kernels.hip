@@ -472,6 +472,123 @@ __global__ __launch_bounds__(256) void stem3s2_u8_h(StemArgs a) {
     }
 }
 
+// The fp32 stem for k 3 / stride 2 / pad 1 with the same staging as stem3s2_u8_h: aligned dwords (4 loads per thread, a dword is wholly
+// inside or outside the image; outside it is loaded as 0 and lut[0] = 0.f is the padding value, so the conversion has no edge case), tile
+// byte c at float index c + 1 of a 104-float LDS row (one ds_write_b128 per dword), A operand from a host-prepared table
+// (stem3_weight_frags_f32: 7 coalesced loads per lane instead of 7 gathered ones and their index arithmetic), couts permuted over the MFMA
+// rows so that a lane stores 4 CT consecutive channels.  The MFMA chain is the general kernel's: k = (kh, kw, byte channel) ascending in
+// steps of four, the oracle's det_stem order -- same operands, same order, same bits.
+void stem3_weight_frags_f32(const float* w_oihw, int cout, std::vector<float>& out) {
+    const int CT = (cout + 15) / 16;
+    out.assign((size_t)CT * 7 * 64, 0.f);
+    for (int ct = 0; ct < CT; ++ct)
+        for (int s = 0; s < 7; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int g = lane >> 4, r16 = lane & 15, k = 4 * s + g;
+                const int co = 4 * CT * (r16 >> 2) + 4 * ct + (r16 & 3);
+                if (k >= 27 || co >= cout) continue;
+                const int tap = k / 3, cb = k % 3;
+                out[((size_t)ct * 7 + s) * 64 + lane] = w_oihw[((size_t)co * 3 + (2 - cb)) * 9 + tap];
+            }
+}
+
+template <int CT>
+__global__ __launch_bounds__(256) void stem3s2_u8_f32(StemArgs a) {
+    constexpr int TIN = 2 * (STEM_TO - 1) + 3, ROW = 104, PT = 4, NDW = 26, NIT = TIN * NDW, NS = 7;
+    __shared__ __attribute__((aligned(16))) float tin[TIN * ROW];
+    __shared__ float lut[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    lut[tid] = a.lut[tid];
+    const int tiles_x = (a.Wout + STEM_TO - 1) / STEM_TO, tiles_y = (a.Hout + STEM_TO - 1) / STEM_TO;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int oy0 = ty * STEM_TO, ox0 = tx * STEM_TO;
+    const int iy0 = oy0 * 2 - 1, gd0 = (ox0 * 2 - 1) * 3 - 1;  // first tile row; byte (in its image row) of the row's first dword: 96 tx - 4
+    const uint8_t* img = a.img + (size_t)b * a.H * a.W * 3;
+    const int wrow = a.W * 3;
+    unsigned dw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int it = tid + 256 * u;
+        const int iy = it / NDW, m = it - iy * NDW;
+        const int gy = iy0 + iy, gd = gd0 + 4 * m;
+        const bool in = it < NIT && (unsigned)gy < (unsigned)a.H && gd >= 0 && gd + 4 <= wrow;
+        const unsigned v = *(const unsigned*)(img + (in ? gy * wrow + gd : 0));
+        dw[u] = in ? v : 0u;
+    }
+    float wa[NS][CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) wa[s][ct] = ((const float*)a.wfrag)[((size_t)ct * NS + s) * 64 + lane];
+    int koff[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int k = 4 * s + g;                                // k / 9 and k % 9 with s a constant and g < 4: no division
+        const int kh = (k >= 9) + (k >= 18), r = k - 9 * kh;
+        koff[s] = k < 27 ? kh * ROW + r : 0;
+    }
+    __syncthreads();                                            // lut visible
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int it = tid + 256 * u;
+        const int iy = it / NDW, m = it - iy * NDW;
+        f32x4 v;
+        v[0] = lut[dw[u] & 255u]; v[1] = lut[(dw[u] >> 8) & 255u]; v[2] = lut[(dw[u] >> 16) & 255u]; v[3] = lut[dw[u] >> 24];
+        if (it < NIT) *(f32x4*)(tin + iy * ROW + 4 * m) = v;
+    }
+    __syncthreads();
+    int base[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) base[pt] = (wave * PT + pt) * 2 * ROW + (lane & 15) * 6 + 1;
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float xb[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) xb[pt] = tin[base[pt] + koff[s]];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+                acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][ct], xb[pt], acc[ct][pt], 0, 0, 0);
+    }
+    // ---- epilogue: lane holds channels 4 CT g + 4 ct + j of pixel (row 4*wave + pt, column lane & 15) ----
+    const int c0 = 4 * CT * g;
+    f32x4 bs[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) bs[ct] = *(const f32x4*)(a.bias + c0 + 4 * ct);          // the bias array is padded to 16 CT floats
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int oy = oy0 + wave * PT + pt, ox = ox0 + (lane & 15);
+        if (oy >= a.Hout || ox >= a.Wout) continue;
+        const size_t po = ((size_t)b * a.Hout + oy) * a.Wout + ox;
+        float* d = a.dst + po * a.dst_cs + c0;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = c0 + 4 * ct;
+            if (c >= a.Cout) continue;
+            const f32x4 v = acc[ct][pt] + bs[ct];
+            f32x4 o;
+            if (a.fast_act) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = silu_fast(v[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = silu_m(v[j]);
+            }
+            if (c + 3 < a.Cout) *(f32x4*)(d + 4 * ct) = o;
+            else for (int j = 0; j < 4 && c + j < a.Cout; ++j) d[4 * ct + j] = o[j];
+        }
+    }
+}
+
 template <int KS>
 static bool launch_stem_mfma(const StemArgs& a, unsigned grid, hipStream_t st) {
     const int tin = (STEM_TO - 1) * a.stride + KS;
@@ -479,7 +596,18 @@ static bool launch_stem_mfma(const StemArgs& a, unsigned grid, hipStream_t st) {
     if (lds > 64 * 1024) return false;
     const int ct = (a.Cout + 15) / 16;
     static const bool h_stem = !getenv("MI355_STEM_F16") || atoi(getenv("MI355_STEM_F16")) != 0;
-    static const bool h_lean = !getenv("MI355_STEM_LEAN") || atoi(getenv("MI355_STEM_LEAN")) != 0;
+    const char* lean_env = getenv("MI355_STEM_LEAN");             // read per launch: the tests switch it
+    const bool h_lean = !lean_env || atoi(lean_env) != 0;
+    if (!a.out_half && KS == 3 && a.stride == 2 && a.pad == 1 && a.wfrag && !(a.W & 3) && !((uintptr_t)a.img & 3) && h_lean) {
+        switch (ct) {
+            case 1: hipLaunchKernelGGL((stem3s2_u8_f32<1>), dim3(grid), dim3(256), 0, st, a); return true;
+            case 2: hipLaunchKernelGGL((stem3s2_u8_f32<2>), dim3(grid), dim3(256), 0, st, a); return true;
+            case 3: hipLaunchKernelGGL((stem3s2_u8_f32<3>), dim3(grid), dim3(256), 0, st, a); return true;
+            case 4: hipLaunchKernelGGL((stem3s2_u8_f32<4>), dim3(grid), dim3(256), 0, st, a); return true;
+            case 5: hipLaunchKernelGGL((stem3s2_u8_f32<5>), dim3(grid), dim3(256), 0, st, a); return true;
+            default: return false;
+        }
+    }
     if (a.out_half && KS == 3 && a.stride == 2 && a.pad == 1 && a.wfrag && !(a.W & 3) && !((uintptr_t)a.img & 3) && (a.variant & 255) != 1 &&
         (h_lean || (a.variant & 255) == 2)) {
         switch (ct) {

@@ -217,15 +217,21 @@ def test_stem_matches_torch(k, cout, h, w):
     np.testing.assert_allclose(y, ref.permute(0, 2, 3, 1).numpy(), rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("k,cout,h,w", [(3, 16, 64, 96), (3, 48, 32, 32), (6, 16, 64, 64), (3, 32, 640, 640)])
-def test_stem_bit_exact_vs_canonical_order_oracle(k, cout, h, w):
+@pytest.mark.parametrize("k,cout,h,w", [(3, 16, 64, 96), (3, 48, 32, 32), (6, 16, 64, 64), (3, 32, 640, 640), (3, 16, 34, 36), (3, 18, 34, 38),
+                                       (3, 80, 32, 64)])
+def test_stem_bit_exact_vs_canonical_order_oracle(k, cout, h, w, monkeypatch):
+    """Both stem kernels (misc_kernels.hip: stem3s2_u8_f32 for k 3 / stride 2 on widths that are multiples of 4, stem_mfma_u8 for the
+    rest and under MI355_STEM_LEAN=0) against the oracle's fma chain; ragged tiles, a width of 38 and a ragged cout among the shapes."""
     from cvsd_amd import ops
     from oracle import det
     rng = np.random.default_rng(k + cout + 7)
     img = rng.integers(0, 256, size=(2, h, w, 3), dtype=np.uint8)
     wt = (rng.standard_normal((cout, 3, k, k)) / np.sqrt(3 * k * k)).astype(np.float32)
     b = rng.standard_normal(cout).astype(np.float32)
-    np.testing.assert_array_equal(ops.stem(img, wt, b, stride=2), det.stem(img, wt, b, stride=2))
+    want = det.stem(img, wt, b, stride=2)
+    np.testing.assert_array_equal(ops.stem(img, wt, b, stride=2), want)
+    monkeypatch.setenv("MI355_STEM_LEAN", "0")
+    np.testing.assert_array_equal(ops.stem(img, wt, b, stride=2), want)
 
 
 @pytest.mark.parametrize("h,w", [(240, 320), (720, 1280), (480, 640), (100, 37), (640, 640), (1080, 1920)])
