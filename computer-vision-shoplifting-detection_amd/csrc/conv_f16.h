@@ -201,55 +201,92 @@ __device__ __forceinline__ void store_tiles_f16_v2(const OutF16& o, f32x4 (&acc)
         }
         return;
     }
+    // Residual reads of PG pixel tiles are ALL issued before the first of them is used (round 4): the epilogue used to load each tile's
+    // residual right where it was added, one memory latency per pixel tile and, in the persistent kernels, per unit -- the 48-channel
+    // bottlenecks of config 5 took 244 us with the residual against 160 us without.  PG = all pixel tiles for small register tiles, 2 for
+    // the large ones (a 16-byte residual per tile pair and pixel tile is 4 registers).
+    constexpr int PG = (CT * PT <= 12) ? PT : (PT % 2 == 0 ? 2 : 1);
+    static_assert(PT % PG == 0, "pixel tiles come in whole groups");
     if (pairs && (CT % 2 == 0)) {
         // ct0 is even: tiles (ct, ct + 1) are a pair -> 8 consecutive couts per lane, one 16-byte fp16 store; pair j at byte 64 j
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            const unsigned dvo = pix[pt] >= 0 ? (unsigned)__mul24(pix[pt], o.dst_cs) * 2u + g * 16u : kOOB;
-            const unsigned rvo = pix[pt] >= 0 ? (unsigned)__mul24(pix[pt], o.res_cs) * 2u + g * 16u : kOOB;
+        for (int pt0 = 0; pt0 < PT; pt0 += PG) {
+            f16x8 rvp[PG][CT / 2];
+            if (o.has_res) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ct += 2) {
-                const int t = ct0 + ct;
-                if (t * 16 >= o.Cout) continue;                           // pairs: Cout % 32 == 0, so a pair is whole or absent
-                const f32x4 v0 = bias_act4(acc[ct][pt], bias4[ct], o.act), v1 = bias_act4(acc[ct + 1][pt], bias4[ct + 1], o.act);
-                f32x4 w0 = v0, w1 = v1;
-                if (o.has_res) {
-                    const f16x8 rv = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(o.rrs, (int)rvo, (t >> 1) * 64, 0));
+                for (int p = 0; p < PG; ++p) {
+                    const unsigned rvo = pix[pt0 + p] >= 0 ? (unsigned)__mul24(pix[pt0 + p], o.res_cs) * 2u + g * 16u : kOOB;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { w0[i] += (float)rv[i]; w1[i] += (float)rv[4 + i]; }
+                    for (int ct = 0; ct < CT; ct += 2)
+                        rvp[p][ct / 2] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(o.rrs, (int)((ct0 + ct) * 16 < o.Cout ? rvo : kOOB),
+                                                                                                         ((ct0 + ct) >> 1) * 64, 0));
                 }
-                f16x8 h;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { h[i] = (_Float16)w0[i]; h[4 + i] = (_Float16)w1[i]; }
-                buffer_store_b128(__builtin_bit_cast(u32x4, h), o.drs, (int)dvo, (t >> 1) * 64);
             }
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < PG; ++p) {
+                const int pt = pt0 + p;
+                const unsigned dvo = pix[pt] >= 0 ? (unsigned)__mul24(pix[pt], o.dst_cs) * 2u + g * 16u : kOOB;
+#pragma unroll
+                for (int ct = 0; ct < CT; ct += 2) {
+                    const int t = ct0 + ct;
+                    if (t * 16 >= o.Cout) continue;                           // pairs: Cout % 32 == 0, so a pair is whole or absent
+                    const f32x4 v0 = bias_act4(acc[ct][pt], bias4[ct], o.act), v1 = bias_act4(acc[ct + 1][pt], bias4[ct + 1], o.act);
+                    f32x4 w0 = v0, w1 = v1;
+                    if (o.has_res) {
+                        const f16x8 rv = rvp[p][ct / 2];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { w0[i] += (float)rv[i]; w1[i] += (float)rv[4 + i]; }
+                    }
+                    f16x8 h;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { h[i] = (_Float16)w0[i]; h[4 + i] = (_Float16)w1[i]; }
+                    buffer_store_b128(__builtin_bit_cast(u32x4, h), o.drs, (int)dvo, (t >> 1) * 64);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         return;
     }
     // single tiles, 8-byte fp16 stores: tile t starts at cout 16 t (lane group at + 4 g), or -- paired layout, odd CT -- at
     // 32 (t >> 1) + 4 (t & 1) (lane group at + 8 g)
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
+    for (int pt0 = 0; pt0 < PT; pt0 += PG) {
         const unsigned lane_b = pairs ? g * 16u : g * 8u;
-        const unsigned dvo = pix[pt] >= 0 ? (unsigned)__mul24(pix[pt], o.dst_cs) * 2u + lane_b : kOOB;
-        const unsigned rvo = pix[pt] >= 0 ? (unsigned)__mul24(pix[pt], o.res_cs) * 2u + lane_b : kOOB;
+        f16x4 rvs[PG][CT];
+        if (o.has_res) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const int t = ct0 + ct;
-            if (t * 16 >= o.Cout) continue;
-            const int so = pairs ? (t >> 1) * 64 + (t & 1) * 8 : t * 32;   // bytes, wave-uniform
-            if (t >= n_full) { ragged(acc[ct][pt], bias4[ct], t * 16 + 4 * (int)g, dvo, rvo, so); continue; }
-            f32x4 v = bias_act4(acc[ct][pt], bias4[ct], o.act);
-            if (o.has_res) {
-                const f16x4 rv = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(o.rrs, (int)rvo, so, 0));
-                v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
+            for (int p = 0; p < PG; ++p) {
+                const unsigned rvo = pix[pt0 + p] >= 0 ? (unsigned)__mul24(pix[pt0 + p], o.res_cs) * 2u + lane_b : kOOB;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int t = ct0 + ct;
+                    const int so = pairs ? (t >> 1) * 64 + (t & 1) * 8 : t * 32;
+                    rvs[p][ct] = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(o.rrs, (int)(t < n_full ? rvo : kOOB), so, 0));   // ragged tiles read their own
+                }
             }
-            f16x4 h;
-            h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), o.drs, (int)dvo, so, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < PG; ++p) {
+            const int pt = pt0 + p;
+            const unsigned dvo = pix[pt] >= 0 ? (unsigned)__mul24(pix[pt], o.dst_cs) * 2u + lane_b : kOOB;
+            const unsigned rvo = pix[pt] >= 0 ? (unsigned)__mul24(pix[pt], o.res_cs) * 2u + lane_b : kOOB;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int t = ct0 + ct;
+                if (t * 16 >= o.Cout) continue;
+                const int so = pairs ? (t >> 1) * 64 + (t & 1) * 8 : t * 32;   // bytes, wave-uniform
+                if (t >= n_full) { ragged(acc[ct][pt], bias4[ct], t * 16 + 4 * (int)g, dvo, rvo, so); continue; }
+                f32x4 v = bias_act4(acc[ct][pt], bias4[ct], o.act);
+                if (o.has_res) {
+                    const f16x4 rv = rvs[p][ct];
+                    v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
+                }
+                f16x4 h;
+                h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), o.drs, (int)dvo, so, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
