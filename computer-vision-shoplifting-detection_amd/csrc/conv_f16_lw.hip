@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lw_f16(ConvKArgs a) {
     const unsigned g = (unsigned)lane >> 4;
 
     // What-if diagnostics, built only with -DMI355_F16_DIAG=1 (tools/ab_build.sh), selected by MI355_F16_EXP: 1 no global loads, 2 no LDS writes,
-    // 4 no stores, 8 weight fragments not re-read from LDS, 16 pixel fragments not re-read, 32 no barriers
+    // 4 no stores, 8 weight fragments not re-read from LDS, 16 pixel fragments not re-read, 32 no barriers, 64 no bias load in the epilogue
 #ifdef MI355_F16_DIAG
     const int exp_flags = a.lds_buf_floats;
 #else
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lw_f16(ConvKArgs a) {
         for (int ct = 0; ct < CT; ++ct) {
             const int ctile = (ct0 + ct) < a.n_ctiles ? (ct0 + ct) : (a.n_ctiles - 1);
             bias4[ct] = *(const f32x4*)(a.bias + tile_cout0(ctile, lane >> 4, conv_f16_pairs(a.Cout)));
+            if (exp_flags & 64) bias4[ct] = (f32x4){0.01f, 0.02f, 0.03f, 0.04f};      // what-if: no bias load in the epilogue
         }
         if (exp_flags & 4) {
 #pragma unroll
